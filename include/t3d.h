@@ -1,0 +1,185 @@
+/*
+ * t3d.h -- C ABI of libt3d_hip.so, the MI355X (gfx950) implementation of the T3DR "Photon"
+ * ray-tracing path.
+ *
+ * The reference renderer is pure Python and has no FFI: its boundary is the Python class API
+ * (Photon(scene, options).render(), T3DR.py:501-1242).  Each entry point below names the
+ * reference function(s) it takes over.  Conventions: every function returns 0 on success or a
+ * negative T3D_E_* code; t3d_last_error() gives the text; no exception crosses the ABI; all
+ * pointers are plain host pointers unless the name says "device"; the library copies what it
+ * needs during the call, the caller keeps ownership of everything it passes in.
+ * One host thread per context.
+ */
+#ifndef T3D_H
+#define T3D_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T3D_ABI_VERSION 1
+
+enum {
+    T3D_OK = 0,
+    T3D_E_INVALID = -1,   /* bad argument (null pointer, size out of range, no scene)      */
+    T3D_E_DEVICE = -2,    /* HIP runtime error                                              */
+    T3D_E_NOMEM = -3,     /* device or host allocation failed                               */
+    T3D_E_CAPACITY = -4,  /* a fixed capacity (trace depth, node buffer) would be exceeded  */
+    T3D_E_CANCELLED = -5  /* the cancel callback asked to stop                              */
+};
+
+/* object kinds: Object.type strings of T3DE.py:960, 1218, 1251, 1261, 1279 */
+enum { T3D_OBJ_MESH = 0, T3D_OBJ_SPHERE = 1, T3D_OBJ_LIGHT = 2, T3D_OBJ_OTHER = 3 /* camera, empty */ };
+
+/* random-number modes for bounce()/transmit() (T3DR.py:740, T3DR.py:937) */
+enum {
+    T3D_RNG_KEYED = 0,     /* counter-based, see raytracing_amd/keyed_rng.py; the only mode the GPU has */
+    T3D_RNG_MT_SERIAL = 1  /* CPython random.seed(seed) stream, depth-first row-major (CPU oracle only) */
+};
+
+/*
+ * Flattened scene: what Photon.render() sees after deepcopy + Object.setTransforms()
+ * (T3DR.py:1090-1100, T3DE.py:1057-1071), in scene.objects order.  Geometry is float64 exactly
+ * as the reference holds it; the HIP library rounds to float32 when it builds device buffers.
+ */
+typedef struct t3d_scene_desc {
+    int32_t n_objects;
+    const int32_t* obj_type;      /* [O]   T3D_OBJ_*                                               */
+    const int32_t* obj_tri_begin; /* [O]   first triangle of a mesh object in tri_*                */
+    const int32_t* obj_tri_count; /* [O]   number of faces (0 unless mesh)                         */
+    const double* obj_center;     /* [O*3] Object.position (sphere/light centre)                   */
+    const double* obj_radius;     /* [O]   scale.x / 2            (T3DR.py:574)                    */
+    const double* obj_ior;        /* [O]   material.ior           (T3DR.py:911)                    */
+    const double* obj_strength;   /* [O]   Light.strength         (T3DR.py:812, 1018)              */
+    const int32_t* obj_shader0;   /* [O]   index of shaders[0] in shader_*; -1 if none             */
+
+    int32_t n_tris;
+    const double* tri_verts;      /* [T*9] v0,v1,v2 world space (baked), faces in mesh.faces order */
+    const int32_t* tri_shader;    /* [T]   shader of the face, Object.getShader rule T3DE.py:1046  */
+
+    int32_t n_shaders;
+    const double* shader_color;   /* [K*3] Shader.color r,g,b                                      */
+    const double* shader_rough;   /* [K]   roughness                                               */
+    const double* shader_refl;    /* [K]   reflectivity                                            */
+    const double* shader_emis;    /* [K]   emissionStrength                                        */
+
+    int32_t n_lights;             /* Photon.getAllLightsPos() list, T3DR.py:789-816                */
+    const double* light_pos;      /* [L*3]                                                         */
+    const double* light_strength; /* [L]                                                           */
+    const double* light_color;    /* [L*3]                                                         */
+
+    double cam_pos[3];            /* Camera.position                                               */
+    double cam_euler[3];          /* Camera.rotation (x,y,z radians), matrix = Rz*Ry*Rx T3DE.py:70 */
+    double cam_zlen;              /* camera.length / 20          (T3DR.py:540)                     */
+} t3d_scene_desc;
+
+/* Photon options that influence pixels (T3DR.py:519-525) plus the additive keys seed / rng_mode. */
+typedef struct t3d_opts {
+    int32_t width, height;
+    int32_t bounces;
+    int32_t samples;    /* used only when bounces > 1 (T3DR.py:1209)                               */
+    int32_t lights;     /* options['lights']: primary rays see Light objects / stop at emitters    */
+    int32_t rng_mode;   /* T3D_RNG_*                                                               */
+    uint32_t seed;
+    int32_t use_bvh;    /* options['bvh'];  results do not depend on it (conservative culling)     */
+    int32_t use_aabb;   /* options['aabb']; likewise                                               */
+    int32_t reserved;
+    double ambient[3];  /* options['ambient'] r,g,b                                                */
+} t3d_opts;
+
+typedef struct t3d_stats {
+    uint64_t rays_api;     /* Rendered.rays: primary samples + shadow rays (T3DR.py:842, 1211)      */
+    uint64_t queries;      /* closest-hit queries: primary + bounce + transmit + shadow             */
+    uint64_t tri_tests;    /* ray-triangle tests executed                                           */
+    uint64_t sphere_tests; /* ray-sphere tests executed                                             */
+    uint64_t aabb_tests;   /* ray-box tests executed                                                */
+    uint64_t nodes;        /* trace-tree nodes created (hits)                                       */
+    double ms_device;      /* device time of the whole call, HIP events on the library's stream     */
+    double ms_trace;       /* of which: closest-hit kernels (trace + shadow)                        */
+    double ms_resolve;     /* of which: colour resolve + image store                                */
+    uint64_t launches;     /* kernel launches issued                                                */
+} t3d_stats;
+
+/* One trace-tree node as t3d_trace_pixel returns it (TraceTreeNode, T3DE.py:273-280). */
+typedef struct t3d_node {
+    int32_t heap;        /* 1 = primary, 2n = bounce child (left), 2n+1 = transmit child (right)   */
+    int32_t obj;         /* index into scene.objects                                               */
+    int32_t face;        /* face index in the mesh, -1 for spheres and lights                      */
+    int32_t direction;   /* 0 = front hit, 1 = back hit                                            */
+    float t;
+    float point[3];
+    float normal[3];     /* as stored by the reference: un-normalised for faces, unit for spheres  */
+    float ray_start[3];
+    float ray_dir[3];
+    float ray_ior;
+    int32_t ray_obj;     /* object the ray travels inside, -1 = none                               */
+    float color[3];      /* computeColor() of the sub-tree (T3DR.py:1004-1083)                     */
+} t3d_node;
+
+typedef struct t3d_ctx t3d_ctx;
+
+/* number of HIP devices visible to the process (<0: error code). */
+int t3d_device_count(void);
+
+/* Create a context bound to one device; takes over "Photon.__init__" state (T3DR.py:501-506). */
+int t3d_create(int device, t3d_ctx** out);
+void t3d_destroy(t3d_ctx* ctx);
+const char* t3d_last_error(const t3d_ctx* ctx); /* ctx may be NULL: error of a failed t3d_create */
+
+/*
+ * Flattening step, device side: converts the description to float32 SoA device buffers
+ * (pre-transformed triangles, spheres, lights, shaders, camera).  Replaces the per-render
+ * deepcopy / setTransforms / buildBVH preparation of Photon.render (T3DR.py:1090-1107).
+ */
+int t3d_upload_scene(t3d_ctx* ctx, const t3d_scene_desc* scene);
+
+/*
+ * Render image rows [row0, row0+nrows): Photon.renderStripe (T3DR.py:1183-1242) with everything
+ * under it (pixelToVector, getRay, trace, computeColor, getDirectLight, getFirstCollision).
+ *   bgr_out       [nrows*W*3] uint8, B,G,R per pixel like the stripe array (T3DR.py:1219-1221)
+ *   radiance_out  [nrows*W*3] float, mean sample colour before the floor (nullable)
+ *   primary_out   [nrows*W*2] int32 (object index, face index) of sample 0's primary hit,
+ *                 -1,-1 for a miss, face -1 for spheres/lights (nullable)
+ *   primary_t_out [nrows*W]   float distance of that hit, NaN for a miss (nullable)
+ * The result does not depend on how rows are split into calls (keyed random numbers).
+ */
+int t3d_render_rows(t3d_ctx* ctx, const t3d_opts* opts, int row0, int nrows, uint8_t* bgr_out,
+                    float* radiance_out, int32_t* primary_out, float* primary_t_out,
+                    t3d_stats* stats);
+
+/*
+ * Same work, outputs left in device memory owned by the caller (e.g. a torch tensor's data
+ * pointer) and launched on `stream` (a hipStream_t passed as void*, NULL = the context's own
+ * stream).  Does not synchronise unless `stats` is non-NULL.
+ */
+int t3d_render_rows_device(t3d_ctx* ctx, const t3d_opts* opts, int row0, int nrows,
+                           uint8_t* bgr_device, float* radiance_device, int32_t* primary_device,
+                           float* primary_t_device, void* stream, t3d_stats* stats);
+
+/*
+ * Trace one pixel sample and return its tree (Photon.trace + computeColor for one initial ray;
+ * serves Rendered.traces[(x, y)][sample] lazily, T3DR.py:1210-1216).  Returns the number of
+ * nodes written (>= 0), nodes in depth-first order with the bounce child before the transmit
+ * child, or a negative error.
+ */
+int t3d_trace_pixel(t3d_ctx* ctx, const t3d_opts* opts, int x, int y, int sample, t3d_node* nodes,
+                    int capacity);
+
+/*
+ * Closest hit for n arbitrary rays (Photon.getFirstCollision, T3DR.py:654-730; used for picking,
+ * explorer.py:1351-1355).  origins/dirs [n*3] (dirs are normalised by the library like
+ * Ray.__init__, T3DE.py:128); out_obj/out_face [n] (-1 = miss), out_t [n], out_dirflag [n]
+ * (0 front, 1 back), out_normal [n*3] (nullable).
+ */
+int t3d_closest_hits(t3d_ctx* ctx, int n, const float* origins, const float* dirs, int lights,
+                     int back_cull, int32_t* out_obj, int32_t* out_face, float* out_t,
+                     int32_t* out_dirflag, float* out_normal);
+
+int t3d_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T3D_H */
