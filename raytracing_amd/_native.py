@@ -1,0 +1,167 @@
+"""ctypes binding of libt3d_hip.so (the C ABI declared in include/t3d.h).
+
+There is no fallback: if the library is missing or no MI355X is visible, every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .flatten import FlatScene, Opts, SceneDesc, Stats, make_opts
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libt3d_hip.so")
+ABI_VERSION = 1
+
+SYMBOLS = ("t3d_abi_version", "t3d_device_count", "t3d_create", "t3d_destroy", "t3d_last_error",
+           "t3d_upload_scene", "t3d_render_rows", "t3d_render_rows_device", "t3d_trace_pixel",
+           "t3d_closest_hits")
+
+
+class NativeError(RuntimeError):
+    """The HIP library is missing, failed to load, or a call into it failed."""
+
+
+class Node(C.Structure):
+    """ctypes mirror of ``t3d_node``."""
+    _fields_ = [("heap", C.c_int32), ("obj", C.c_int32), ("face", C.c_int32), ("direction", C.c_int32),
+                ("t", C.c_float), ("point", C.c_float * 3), ("normal", C.c_float * 3),
+                ("ray_start", C.c_float * 3), ("ray_dir", C.c_float * 3), ("ray_ior", C.c_float),
+                ("ray_obj", C.c_int32), ("color", C.c_float * 3)]
+
+
+_lib = None
+
+
+def load():
+    """Load libt3d_hip.so once and declare its prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(f"{LIB_PATH} not found: build it with `make -C raytracing_amd/csrc` "
+                          "(or python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise NativeError(f"cannot load {LIB_PATH}: {e}") from e
+    P = C.POINTER
+    lib.t3d_abi_version.restype = C.c_int
+    lib.t3d_device_count.restype = C.c_int
+    lib.t3d_create.restype = C.c_int
+    lib.t3d_create.argtypes = [C.c_int, P(C.c_void_p)]
+    lib.t3d_destroy.restype = None
+    lib.t3d_destroy.argtypes = [C.c_void_p]
+    lib.t3d_last_error.restype = C.c_char_p
+    lib.t3d_last_error.argtypes = [C.c_void_p]
+    lib.t3d_upload_scene.restype = C.c_int
+    lib.t3d_upload_scene.argtypes = [C.c_void_p, P(SceneDesc)]
+    lib.t3d_render_rows.restype = C.c_int
+    lib.t3d_render_rows.argtypes = [C.c_void_p, P(Opts), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, P(Stats)]
+    lib.t3d_render_rows_device.restype = C.c_int
+    lib.t3d_render_rows_device.argtypes = [C.c_void_p, P(Opts), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, P(Stats)]
+    lib.t3d_trace_pixel.restype = C.c_int
+    lib.t3d_trace_pixel.argtypes = [C.c_void_p, P(Opts), C.c_int, C.c_int, C.c_int, P(Node), C.c_int]
+    lib.t3d_closest_hits.restype = C.c_int
+    lib.t3d_closest_hits.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    if lib.t3d_abi_version() != ABI_VERSION:
+        raise NativeError(f"libt3d_hip.so has ABI version {lib.t3d_abi_version()}, expected {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def device_count() -> int:
+    n = load().t3d_device_count()
+    if n < 0:
+        raise NativeError("t3d_device_count failed: no usable HIP runtime")
+    return n
+
+
+def _ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class Context:
+    """One device context (``t3d_ctx``) holding one uploaded scene."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load()
+        handle = C.c_void_p()
+        rc = self._lib.t3d_create(int(device), C.byref(handle))
+        if rc != 0:
+            raise NativeError(f"t3d_create(device={device}) failed ({rc}): "
+                              f"{self._lib.t3d_last_error(None).decode()}")
+        self._h = handle
+        self.device = device
+        self.flat = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.t3d_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise NativeError(f"{what} failed ({rc}): {self._lib.t3d_last_error(self._h).decode()}")
+        return rc
+
+    def upload(self, flat: FlatScene):
+        desc = flat.as_desc()
+        self._check(self._lib.t3d_upload_scene(self._h, C.byref(desc)), "t3d_upload_scene")
+        self.flat = flat
+
+    def render_rows(self, options: dict, seed: int = 0, row0: int = 0, nrows: int | None = None,
+                    want_radiance=False, want_primary=False):
+        """-> dict(bgr uint8 [rows,W,3], radiance, prim [rows,W,2], prim_t, stats dict)"""
+        opts = make_opts(options, seed)
+        W = opts.width
+        nrows = opts.height - row0 if nrows is None else nrows
+        bgr = np.empty((nrows, W, 3), np.uint8)
+        rad = np.empty((nrows, W, 3), np.float32) if want_radiance else None
+        prim = np.empty((nrows, W, 2), np.int32) if want_primary else None
+        prim_t = np.empty((nrows, W), np.float32) if want_primary else None
+        stats = Stats()
+        self._check(self._lib.t3d_render_rows(self._h, C.byref(opts), row0, nrows, _ptr(bgr), _ptr(rad), _ptr(prim),
+                                              _ptr(prim_t), C.byref(stats)), "t3d_render_rows")
+        return dict(bgr=bgr, radiance=rad, prim=prim, prim_t=prim_t, stats=stats.as_dict())
+
+    def render_rows_device(self, options: dict, seed: int, row0: int, nrows: int, bgr_ptr: int, radiance_ptr: int = 0,
+                           primary_ptr: int = 0, primary_t_ptr: int = 0, stream: int = 0, want_stats=True):
+        """Outputs go to caller-owned device memory (raw addresses, e.g. ``tensor.data_ptr()``)."""
+        opts = make_opts(options, seed)
+        stats = Stats() if want_stats else None
+        self._check(self._lib.t3d_render_rows_device(
+            self._h, C.byref(opts), row0, nrows, C.c_void_p(bgr_ptr), C.c_void_p(radiance_ptr or None),
+            C.c_void_p(primary_ptr or None), C.c_void_p(primary_t_ptr or None), C.c_void_p(stream or None),
+            C.byref(stats) if stats is not None else None), "t3d_render_rows_device")
+        return stats.as_dict() if stats is not None else None
+
+    def trace_pixel(self, options: dict, x: int, y: int, sample: int = 0, seed: int = 0):
+        opts = make_opts(options, seed)
+        cap = min(65536, (1 << (opts.bounces + 1)) - 1)
+        buf = (Node * cap)()
+        n = self._check(self._lib.t3d_trace_pixel(self._h, C.byref(opts), x, y, sample, buf, cap), "t3d_trace_pixel")
+        return [buf[i] for i in range(n)]
+
+    def closest_hits(self, origins, dirs, lights=True, back_cull=True):
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        n = len(o)
+        obj, face, dirflag = (np.empty(n, np.int32) for _ in range(3))
+        t = np.empty(n, np.float32)
+        normal = np.empty((n, 3), np.float32)
+        self._check(self._lib.t3d_closest_hits(self._h, n, _ptr(o), _ptr(d), int(lights), int(back_cull), _ptr(obj),
+                                               _ptr(face), _ptr(t), _ptr(dirflag), _ptr(normal)), "t3d_closest_hits")
+        return dict(obj=obj, face=face, t=t, direction=dirflag, normal=normal)

@@ -1,0 +1,1043 @@
+// t3d_hip.hip -- libt3d_hip.so: the T3DR "Photon" ray-tracing path on MI355X (gfx950, wave64).
+//
+// Structure: a wavefront (queue based) tracer.  One render call processes a band of image rows
+// level by level of the trace tree (T3DR.py:959-1001):
+//
+//   for depth d = 0 .. bounces:
+//       k_trace   one thread per ray of level d: closest hit over all primitives, classify the
+//                 hit (miss / emitter leaf / shaded node), append the shaded node to the level's
+//                 node array and the reflected / transmitted child rays to the next level's ray
+//                 queue (wave64 ballot + prefix popcount, one atomic per wave)
+//       k_shade   one thread per shaded node of level d: one closest-hit shadow query per light,
+//                 accumulates the direct-light intensity (T3DR.py:820-900)
+//   for depth d = bounces .. 0:
+//       k_resolve one thread per node: computeColor (T3DR.py:1004-1083) from the two child slots
+//                 and the direct light, pushes the colour into the parent's slot
+//   k_finish      per pixel: mean over samples, floor, clamp, BGR8 store (T3DR.py:1219-1221)
+//
+// The colour of a node is a clamped (non-linear) function of its children, so the tree is kept in
+// HBM and resolved bottom-up; a throughput-accumulating path tracer would not give the same image.
+//
+// All arithmetic is float32.  Triangles are tested through a per-triangle affine map prepared on
+// the host in float64 (plane row + two barycentric rows, 12 floats): t from the plane equation
+// like Ray.getTPlane (T3DE.py:133-142), then u, v of the hit point; the strict interior test of
+// Photon.pointWithinTriangle (T3DR.py:601-621) becomes u > 0, v > 0, u + v < 1.
+// Triangle rows are read with wave-uniform addresses, so they travel through the scalar data path
+// (SGPR operands) and cost no vector memory or LDS bandwidth.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/t3d.h"
+
+#define T3D_BLOCK 256
+#define T3D_MAX_LIGHTS 64
+#define T3D_MAX_BOUNCES 14 /* heap index of the deepest node must fit 16 bits of the RNG key */
+
+// ------------------------------------------------------------------------------------------------
+// device-side scene
+// ------------------------------------------------------------------------------------------------
+struct DevShader {
+    float r, g, b, rough;
+    float refl, emis, pad0, pad1;
+};
+
+struct DevSphere {
+    float cx, cy, cz, r2;  // centre, radius^2
+    int obj;               // index into scene.objects
+    int is_light;          // Light objects are visible only to rays traced with lights = true
+    int shader;            // shaders[0] (for lights: colour holder)
+    float strength;        // Light.strength
+};
+
+struct DevLight {
+    float x, y, z, strength;
+};
+
+struct DevCamera {
+    float pos[3];
+    float m[9];  // Rz*Ry*Rx
+    float zlen;
+};
+
+struct DevScene {
+    int n_tris, n_spheres, n_lights, n_shaders;
+    const float4* tri_rows;    // [3*T]: (n.xyz, n.v0), (a.xyz, aw), (b.xyz, bw)
+    const int4* tri_meta;      // [T]: (object, face-in-mesh, shader, unused)
+    const DevSphere* spheres;  // [S]
+    const DevLight* lights;    // [L]
+    const DevShader* shaders;  // [K]
+    const float* obj_ior;      // [O]
+    DevCamera cam;
+    float light_color[3];  // sum over lights of colour * 0.6 with saturating adds (T3DR.py:893)
+};
+
+struct RenderParams {
+    int width, height, row0, nrows;
+    int bounces, samples, lights;
+    uint32_t seed;
+    float ambient[3];
+    int n0;          // primary samples of this launch (rows * width * samples)
+    int cap;         // capacity of one level's ray queue / node array
+    int want_debug;  // record t3d_node entries (t3d_trace_pixel)
+    int px0, py0, sample0;  // single-pixel mode (t3d_trace_pixel): the only pixel / sample traced
+    int single;
+};
+
+// One queued ray (64 B).
+struct RayRec {
+    float4 o;  // origin, w = ior of the medium the ray travels in
+    float4 d;  // unit direction, w = int bits: object the ray is inside (-1 none)
+    float4 p;  // parent node's ray.start (attenuation origin, T3DR.py:1062-1064), w = int bits: parent node
+    uint4 k;   // x = pixel-sample index, y = heap index, z = side (0 = reflected slot, 1 = transmitted), w = debug parent
+};
+
+// Node arrays (structure of float4 arrays, 64 B per node in total)
+struct NodePool {
+    float4* a;  // P.xyz, attenuation towards the parent
+    float4* b;  // unit normal, w = int bits: shader | side << 30
+    float4* c;  // reflected slot rgb (child colour * attenuation), w = int bits: parent index
+    float4* d;  // transmitted slot rgb, w = direct-light intensity
+    int* dbg;   // debug record index of the node (only in single-pixel mode)
+};
+
+struct Counters {
+    int n_rays[T3D_MAX_BOUNCES + 2];
+    int n_nodes[T3D_MAX_BOUNCES + 2];
+    int overflow;
+    int n_dbg;
+};
+
+// ------------------------------------------------------------------------------------------------
+// small vector helpers
+// ------------------------------------------------------------------------------------------------
+struct V3 {
+    float x, y, z;
+};
+__device__ __forceinline__ V3 mk(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float k) { return mk(a.x * k, a.y * k, a.z * k); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ V3 madd(V3 a, V3 d, float t) {  // a + d * t
+    return mk(fmaf(d.x, t, a.x), fmaf(d.y, t, a.y), fmaf(d.z, t, a.z));
+}
+__device__ __forceinline__ V3 normalize(V3 a) { return a * __builtin_amdgcn_rsqf(dot(a, a)); }
+__device__ __forceinline__ float length(V3 a) { return __builtin_sqrtf(dot(a, a)); }
+
+__device__ __forceinline__ float attenuation(float dist2) {  // getAttenuation(d), T3DR.py:782-785, from d^2
+    float a = __builtin_amdgcn_rcpf(fmaf(0.01f, dist2, 1.0f));
+    return fmaxf(0.0f, fminf(1.0f, a));
+}
+
+// ------------------------------------------------------------------------------------------------
+// keyed random numbers (raytracing_amd/keyed_rng.py)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ V3 keyed_cube(uint32_t seed, uint32_t px, uint32_t py, uint32_t sample, uint32_t heap) {
+    uint32_t h = mix32(seed + 0x9E3779B9u);
+    h = mix32(h ^ px);
+    h = mix32(h ^ py);
+    h = mix32(h ^ (((sample & 0xFFFFu) << 16) | (heap & 0xFFFFu)));
+    uint32_t a = mix32(h ^ 0x9E3779B9u) >> 8, b = mix32(h ^ 0x3C6EF372u) >> 8, c = mix32(h ^ 0xDAA66D2Bu) >> 8;
+    const float s = 1.0f / 8388608.0f;  // 2^-23: -1 + 2 * bits / 2^24, exact in float32
+    return mk(fmaf((float)a, s, -1.0f), fmaf((float)b, s, -1.0f), fmaf((float)c, s, -1.0f));
+}
+
+// ------------------------------------------------------------------------------------------------
+// closest hit: Photon.getFirstCollision (T3DR.py:654-730) over every primitive
+// ------------------------------------------------------------------------------------------------
+struct Hit {
+    float t;
+    int prim;  // < 0 miss; [0, T) triangle; T + s sphere s
+    int back;  // sphere: 1 = hit from inside
+};
+
+__device__ __forceinline__ Hit closest_hit(const float4* __restrict__ tri_rows, int n_tris,
+                                           const DevSphere* __restrict__ spheres, int n_spheres, V3 o, V3 d,
+                                           bool lights, bool back_cull) {
+    float best = __builtin_inff();
+    int prim = -1;
+    int back = 0;
+    // Triangles.  getFaceCollision (T3DR.py:624-651): reject |d.n| < 1e-6, t = (n.v0 - n.o) / (n.d),
+    // reject t < 0, strict interior test, back faces rejected when back_cull.  First hit wins ties.
+#pragma unroll 2
+    for (int i = 0; i < n_tris; ++i) {
+        const float4 rn = tri_rows[3 * i + 0];
+        const float4 ra = tri_rows[3 * i + 1];
+        const float4 rb = tri_rows[3 * i + 2];
+        float dn = fmaf(rn.z, d.z, fmaf(rn.y, d.y, rn.x * d.x));
+        float q = fmaf(rn.z, o.z, fmaf(rn.y, o.y, fmaf(rn.x, o.x, -rn.w)));  // n.o - n.v0
+        float t = -q * __builtin_amdgcn_rcpf(dn);
+        float px = fmaf(d.x, t, o.x), py = fmaf(d.y, t, o.y), pz = fmaf(d.z, t, o.z);
+        float u = fmaf(ra.z, pz, fmaf(ra.y, py, fmaf(ra.x, px, ra.w)));
+        float v = fmaf(rb.z, pz, fmaf(rb.y, py, fmaf(rb.x, px, rb.w)));
+        bool ok = (u > 0.0f) & (v > 0.0f) & (u + v < 1.0f) & (t >= 0.0f) & (t < best) &
+                  (__builtin_fabsf(dn) >= 1e-6f) & ((dn < 0.0f) | !back_cull);
+        best = ok ? t : best;
+        prim = ok ? i : prim;
+    }
+    // Spheres and lights.  getSphereCollision (T3DR.py:572-598), Ray.getTSphere (T3DE.py:145-163).
+    for (int s = 0; s < n_spheres; ++s) {
+        const DevSphere sp = spheres[s];
+        if (sp.is_light && !lights) continue;  // wave-uniform
+        V3 L = mk(o.x - sp.cx, o.y - sp.cy, o.z - sp.cz);
+        float b = dot(L, d);
+        float c = dot(L, L) - sp.r2;
+        float disc = fmaf(b, b, -c);
+        float root = __builtin_sqrtf(fmaxf(disc, 0.0f));
+        float t1 = -b - root, t2 = -b + root;
+        bool front = t1 > 0.0f;
+        bool inside = (!front) & (t2 > 0.0f) & (!back_cull) & (sp.is_light == 0);
+        float t = front ? t1 : t2;
+        bool ok = (disc >= 0.0f) & (front | inside) & (t < best);
+        best = ok ? t : best;
+        prim = ok ? n_tris + s : prim;
+        back = ok ? (front ? 0 : 1) : back;
+    }
+    Hit h;
+    h.t = best; h.prim = prim; h.back = back;
+    return h;
+}
+
+// wave64 compaction: index in [*counter .. ) for every lane with pred, one atomic per wave
+__device__ __forceinline__ int wave_append(int* counter, bool pred) {
+    unsigned long long m = __ballot(pred);
+    if (m == 0ull) return -1;
+    int lane = (int)__lane_id();
+    int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(m));
+    base = __shfl(base, leader);
+    return base + __popcll(m & ((1ull << lane) - 1ull));
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_trace
+// ------------------------------------------------------------------------------------------------
+struct TraceOut {
+    float4* sample_color;  // [N0] rgb of a finished sample (w unused)
+    int32_t* primary;      // [npix*2] or null
+    float* primary_t;      // [npix] or null
+    t3d_node* dbg;         // debug records or null
+    int dbg_cap;
+};
+
+__device__ __forceinline__ void camera_ray(const DevCamera& cam, const RenderParams& rp, int px, int py, V3& o, V3& d) {
+    // pixelToVector (T3DR.py:528-542): pixel corner on the image plane, rotated, translated
+    float w = (float)rp.width, h = (float)rp.height;
+    float ratio = w / h;
+    float x = ((float)px / w) * ratio - ratio * 0.5f;
+    float y = 0.5f - (float)py / h;
+    float z = cam.zlen;
+    // getRay (T3DR.py:545-551): direction = (pixelVec - camera.position), i.e. the rotated offset
+    V3 v = mk(cam.m[0] * x + cam.m[1] * y + cam.m[2] * z, cam.m[3] * x + cam.m[4] * y + cam.m[5] * z,
+              cam.m[6] * x + cam.m[7] * y + cam.m[8] * z);
+    o = mk(cam.pos[0], cam.pos[1], cam.pos[2]);
+    d = normalize(v);
+}
+
+template <bool LEVEL0>
+__global__ __launch_bounds__(T3D_BLOCK) void k_trace(DevScene sc, const float4* __restrict__ tri_rows,
+                                                     const DevSphere* __restrict__ spheres, RenderParams rp, int level,
+                                                     const RayRec* __restrict__ rays_in, RayRec* __restrict__ rays_out,
+                                                     NodePool pool, Counters* cnt, TraceOut out) {
+    const int n = LEVEL0 ? rp.n0 : min(cnt->n_rays[level], rp.cap);
+    const int stride = gridDim.x * blockDim.x;
+    const int base_iter = (n + stride - 1) / stride;
+    const size_t node_base = (size_t)level * rp.cap;
+    for (int it = 0; it < base_iter; ++it) {
+        const int i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        const bool active = i < n;
+        V3 o = mk(0, 0, 0), d = mk(0, 0, 1), pstart = mk(0, 0, 0);
+        float ior = 1.0f;
+        int inside_obj = -1, parent = -1, side = 0, dbg_parent = -1;
+        uint32_t ps = 0, heap = 1;
+        int px = 0, py = 0, smp = 0;
+        if (active) {
+            if (LEVEL0) {
+                ps = (uint32_t)i;
+                int pix = i / rp.samples;
+                smp = i - pix * rp.samples;
+                int ly = pix / rp.width;
+                px = pix - ly * rp.width;
+                py = rp.row0 + ly;
+                if (rp.single) { px = rp.px0; py = rp.py0; smp = rp.sample0; }
+                camera_ray(sc.cam, rp, px, py, o, d);
+                parent = i;
+            } else {
+                RayRec r = rays_in[i];
+                o = mk(r.o.x, r.o.y, r.o.z); ior = r.o.w;
+                d = mk(r.d.x, r.d.y, r.d.z); inside_obj = __float_as_int(r.d.w);
+                pstart = mk(r.p.x, r.p.y, r.p.z); parent = __float_as_int(r.p.w);
+                ps = r.k.x; heap = r.k.y; side = (int)r.k.z; dbg_parent = (int)r.k.w;
+                int pix = (int)ps / rp.samples;
+                smp = (int)ps - pix * rp.samples;
+                int ly = pix / rp.width;
+                px = pix - ly * rp.width;
+                py = rp.row0 + ly;
+                if (rp.single) { px = rp.px0; py = rp.py0; smp = rp.sample0; }
+            }
+        }
+        const bool lights = LEVEL0 ? (rp.lights != 0) : true;
+        const bool back_cull = (ior == 1.0f);  // T3DR.py:961
+        Hit h = closest_hit(tri_rows, sc.n_tris, spheres, sc.n_spheres, o, d, lights, back_cull);
+        const bool hit = active && h.prim >= 0;
+
+        // ---- classify ---------------------------------------------------------------------
+        V3 P = madd(o, d, h.t);
+        V3 N = mk(0, 0, 1);      // unit normal as used by bounce / transmit / direct light
+        V3 Nraw = mk(0, 0, 1);   // normal as the reference stores it (debug records)
+        int obj = -1, face = -1, shader = -1, dirflag = 0;
+        bool emitter = false;
+        V3 emit = mk(0, 0, 0);
+        float strength = 1.0f;
+        if (hit) {
+            if (h.prim < sc.n_tris) {
+                int4 meta = sc.tri_meta[h.prim];
+                float4 rn = tri_rows[3 * h.prim];
+                obj = meta.x; face = meta.y; shader = meta.z;
+                Nraw = mk(rn.x, rn.y, rn.z);
+                N = normalize(Nraw);
+                dirflag = (dot(Nraw, d) < 0.0f) ? 0 : 1;
+                DevShader sh = sc.shaders[shader];
+                emitter = sh.emis > 0.0f;
+                strength = sh.emis;
+            } else {
+                DevSphere sp = spheres[h.prim - sc.n_tris];
+                obj = sp.obj; shader = sp.shader; dirflag = h.back;
+                N = normalize(mk(P.x - sp.cx, P.y - sp.cy, P.z - sp.cz));
+                Nraw = N;
+                emitter = sp.is_light != 0;
+                strength = sp.strength;
+            }
+            if (emitter) {
+                // computeColor for lights / emissive faces (T3DR.py:1014-1041): distance to the camera
+                DevShader sh = sc.shaders[shader];
+                V3 pc = mk(P.x - sc.cam.pos[0], P.y - sc.cam.pos[1], P.z - sc.cam.pos[2]);
+                float att = attenuation(dot(pc, pc));
+                emit = mk(fminf(sh.r * strength * att, 255.0f), fminf(sh.g * strength * att, 255.0f),
+                          fminf(sh.b * strength * att, 255.0f));
+            }
+        }
+        if (LEVEL0 && active) {
+            if (smp == 0 || rp.single) {
+                int pix = rp.single ? 0 : i / rp.samples;
+                if (out.primary) { out.primary[2 * pix] = obj; out.primary[2 * pix + 1] = face; }
+                if (out.primary_t) out.primary_t[pix] = hit ? h.t : __builtin_nanf("");
+            }
+        }
+        // attenuation of this node's colour on its way into the parent: |P - parent.ray.start|
+        V3 pp = P - pstart;
+        const float att_parent = LEVEL0 ? 1.0f : attenuation(dot(pp, pp));
+
+        // ---- debug record (single-pixel mode) ----------------------------------------------
+        int dbg_idx = -1;
+        if (rp.want_debug && hit) {
+            dbg_idx = atomicAdd(&cnt->n_dbg, 1);
+            if (dbg_idx < out.dbg_cap) {
+                t3d_node& nd = out.dbg[dbg_idx];
+                nd.heap = (int)heap; nd.obj = obj; nd.face = face; nd.direction = dirflag; nd.t = h.t;
+                nd.point[0] = P.x; nd.point[1] = P.y; nd.point[2] = P.z;
+                nd.normal[0] = Nraw.x; nd.normal[1] = Nraw.y; nd.normal[2] = Nraw.z;
+                nd.ray_start[0] = o.x; nd.ray_start[1] = o.y; nd.ray_start[2] = o.z;
+                nd.ray_dir[0] = d.x; nd.ray_dir[1] = d.y; nd.ray_dir[2] = d.z;
+                nd.ray_ior = ior; nd.ray_obj = inside_obj;
+                nd.color[0] = emit.x; nd.color[1] = emit.y; nd.color[2] = emit.z;
+            }
+        }
+
+        // ---- leaves -------------------------------------------------------------------------
+        if (active && (!hit || emitter)) {
+            if (LEVEL0) {
+                V3 c = hit ? emit : mk(rp.ambient[0], rp.ambient[1], rp.ambient[2]);  // T3DR.py:1006-1007
+                out.sample_color[i] = make_float4(c.x, c.y, c.z, 0.0f);
+            } else if (hit) {
+                float4* slot = side ? pool.d : pool.c;
+                float4 cur = slot[parent];
+                cur.x = emit.x * att_parent; cur.y = emit.y * att_parent; cur.z = emit.z * att_parent;
+                slot[parent] = cur;
+            }
+        }
+
+        // ---- shaded node --------------------------------------------------------------------
+        const bool shaded = hit && !emitter;
+        int node = wave_append(&cnt->n_nodes[level], shaded);
+        bool stored = shaded && node < rp.cap;
+        if (shaded && !stored) cnt->overflow = 1;
+        if (stored) {
+            const float k = 2.0f / 255.0f;  // absent children count as ambient * 2/255 (T3DR.py:1054-1055)
+            size_t g = node_base + (size_t)node;
+            pool.a[g] = make_float4(P.x, P.y, P.z, att_parent);
+            pool.b[g] = make_float4(N.x, N.y, N.z, __int_as_float(shader | (side << 30)));
+            pool.c[g] = make_float4(rp.ambient[0] * k, rp.ambient[1] * k, rp.ambient[2] * k, __int_as_float(parent));
+            pool.d[g] = make_float4(rp.ambient[0] * k, rp.ambient[1] * k, rp.ambient[2] * k, 0.0f);
+            if (rp.want_debug) pool.dbg[g] = dbg_idx;
+        }
+
+        // ---- children (T3DR.py:979-995) --------------------------------------------------------
+        bool want_t = false, want_b = false;
+        V3 tdir = mk(0, 0, 1), bdir = mk(0, 0, 1), tstart = P, bstart = P;
+        float t_ior = 1.0f;
+        int t_obj = -1;
+        if (stored && level < rp.bounces) {
+            DevShader sh = sc.shaders[shader];
+            float refl = sh.refl, rough = sh.rough;
+            if (refl != 1.0f) {
+                // transmit (T3DR.py:904-956)
+                V3 Nn = N;
+                float n2 = sc.obj_ior[obj];
+                int nobj = obj;
+                if (obj == inside_obj) { Nn = N * -1.0f; n2 = 1.0f; nobj = -1; }
+                float cosI = -dot(d, Nn);
+                float ratio = ior / n2;
+                float sin2T = ratio * ratio * (1.0f - cosI * cosI);
+                if (!(sin2T > 1.0f)) {
+                    float cosT = __builtin_sqrtf(1.0f - sin2T);
+                    V3 spec = madd(d * ratio, Nn, ratio * cosI - cosT);
+                    V3 diff = normalize(keyed_cube(rp.seed, (uint32_t)px, (uint32_t)py, (uint32_t)smp, 2u * heap + 1u));
+                    if (dot(diff, Nn) > 0.0f) diff = diff * -1.0f;
+                    V3 dir = madd(spec * (1.0f - rough), diff, rough);
+                    tstart = madd(P, dir, 0.1f);
+                    tdir = normalize(dir);
+                    t_ior = n2; t_obj = nobj;
+                    want_t = true;
+                }
+            }
+            if (refl != 0.0f) {
+                // bounce (T3DR.py:733-759)
+                V3 diff = normalize(keyed_cube(rp.seed, (uint32_t)px, (uint32_t)py, (uint32_t)smp, 2u * heap));
+                if (dot(diff, N) < 0.0f) diff = diff * -1.0f;
+                V3 spec = madd(d, N, -2.0f * dot(d, N));
+                V3 dir = madd(spec * (1.0f - rough), diff, rough);
+                bstart = madd(P, dir, 0.1f);
+                bdir = normalize(dir);
+                want_b = true;
+            }
+        }
+        int* next_count = &cnt->n_rays[level + 1];
+        int ti = wave_append(next_count, want_t);
+        int bi = wave_append(next_count, want_b);
+        if (want_t) {
+            if (ti < rp.cap) {
+                RayRec r;
+                r.o = make_float4(tstart.x, tstart.y, tstart.z, t_ior);
+                r.d = make_float4(tdir.x, tdir.y, tdir.z, __int_as_float(t_obj));
+                r.p = make_float4(o.x, o.y, o.z, __int_as_float((int)(node_base + node)));
+                r.k = make_uint4(ps, 2u * heap + 1u, 1u, (uint32_t)dbg_idx);
+                rays_out[ti] = r;
+            } else cnt->overflow = 1;
+        }
+        if (want_b) {
+            if (bi < rp.cap) {
+                RayRec r;
+                r.o = make_float4(bstart.x, bstart.y, bstart.z, ior);
+                r.d = make_float4(bdir.x, bdir.y, bdir.z, __int_as_float(inside_obj));
+                r.p = make_float4(o.x, o.y, o.z, __int_as_float((int)(node_base + node)));
+                r.k = make_uint4(ps, 2u * heap, 0u, (uint32_t)dbg_idx);
+                rays_out[bi] = r;
+            } else cnt->overflow = 1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_shade: getDirectLight (T3DR.py:820-900) + getVisibility (T3DR.py:762-778) for one level's nodes
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(T3D_BLOCK) void k_shade(DevScene sc, const float4* __restrict__ tri_rows,
+                                                     const DevSphere* __restrict__ spheres, RenderParams rp, int level,
+                                                     NodePool pool, const Counters* __restrict__ cnt) {
+    const int n = min(cnt->n_nodes[level], rp.cap);
+    const int stride = gridDim.x * blockDim.x;
+    const int iters = (n + stride - 1) / stride;
+    const size_t node_base = (size_t)level * rp.cap;
+    const V3 cam = mk(sc.cam.pos[0], sc.cam.pos[1], sc.cam.pos[2]);
+    for (int it = 0; it < iters; ++it) {
+        const int i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        const bool active = i < n;
+        const size_t g = node_base + (size_t)(active ? i : 0);
+        float4 a = pool.a[g], b = pool.b[g];
+        V3 P = mk(a.x, a.y, a.z), N = mk(b.x, b.y, b.z);
+        int shader = __float_as_int(b.w) & 0x3FFFFFFF;
+        float rough = sc.shaders[shader].rough;
+        V3 view = normalize(cam - P);
+        float total = 0.0f;
+        for (int l = 0; l < sc.n_lights; ++l) {
+            DevLight lt = sc.lights[l];
+            V3 to = mk(lt.x - P.x, lt.y - P.y, lt.z - P.z);
+            float dist2 = dot(to, to);
+            V3 Ld = to * __builtin_amdgcn_rsqf(dist2);
+            V3 start = madd(P, Ld, 0.2f);
+            Hit h = closest_hit(tri_rows, sc.n_tris, spheres, sc.n_spheres, start, Ld, true, false);
+            float vis = 1.0f;
+            if (h.prim >= 0) {
+                if (h.prim < sc.n_tris) {
+                    DevShader bs = sc.shaders[sc.tri_meta[h.prim].z];
+                    if (!(bs.emis > 0.0f)) vis = 1.0f - bs.refl;
+                } else {
+                    DevSphere sp = spheres[h.prim - sc.n_tris];
+                    if (!sp.is_light) vis = 1.0f - sc.shaders[sp.shader].refl;
+                }
+            }
+            float ldn = dot(Ld, N);
+            float diffuse = fmaxf(0.0f, ldn);
+            V3 R = madd(Ld * -1.0f, N, 2.0f * ldn);
+            float spec = (dot(normalize(R), view) < 0.96f) ? 0.0f : 1.0f;
+            float att = attenuation(dist2);
+            total += (diffuse * rough + spec * (1.0f - rough)) * lt.strength * vis * att;
+        }
+        if (active) pool.d[g].w = total;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_resolve: computeColor (T3DR.py:1043-1083) for one level, pushing the result to the parent
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(T3D_BLOCK) void k_resolve(DevScene sc, RenderParams rp, int level, NodePool pool,
+                                                       const Counters* __restrict__ cnt, float4* sample_color,
+                                                       t3d_node* dbg, int dbg_cap) {
+    const int n = min(cnt->n_nodes[level], rp.cap);
+    const size_t node_base = (size_t)level * rp.cap;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const size_t g = node_base + (size_t)i;
+        float4 a = pool.a[g], b = pool.b[g], c = pool.c[g], d = pool.d[g];
+        int meta = __float_as_int(b.w);
+        int shader = meta & 0x3FFFFFFF, side = (meta >> 30) & 1;
+        int parent = __float_as_int(c.w);
+        DevShader sh = sc.shaders[shader];
+        float refl = sh.refl, tf = 1.0f - refl, I = d.w;
+        float col[3] = {sh.r, sh.g, sh.b};
+        float rs[3] = {c.x, c.y, c.z}, ts[3] = {d.x, d.y, d.z};
+        float res[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float indirect = fminf(rs[ch] * refl + ts[ch] * tf * 1.4f, 255.0f);
+            float direct = fminf(col[ch] * I + sc.light_color[ch] * I * (2.0f / 255.0f), 255.0f) * refl;
+            float v = fminf(indirect + direct, 255.0f);
+            res[ch] = fminf(v + col[ch] * rp.ambient[ch] * (1.0f / 255.0f), 255.0f);
+        }
+        if (rp.want_debug) {
+            int di = pool.dbg[g];
+            if (di >= 0 && di < dbg_cap) { dbg[di].color[0] = res[0]; dbg[di].color[1] = res[1]; dbg[di].color[2] = res[2]; }
+        }
+        if (level == 0) {
+            sample_color[parent] = make_float4(res[0], res[1], res[2], 0.0f);
+        } else {
+            float att = a.w;
+            float4* slot = side ? pool.d : pool.c;
+            float4 cur = slot[parent];
+            cur.x = res[0] * att; cur.y = res[1] * att; cur.z = res[2] * att;
+            slot[parent] = cur;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_finish: RGB.mean + clamp + BGR8 (T3DE.py:401-415, T3DR.py:1219-1221)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(T3D_BLOCK) void k_finish(RenderParams rp, const float4* __restrict__ sample_color,
+                                                      uint8_t* __restrict__ bgr, float* __restrict__ radiance) {
+    const int npix = rp.nrows * rp.width;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        float r = 0, g = 0, b = 0;
+        for (int k = 0; k < rp.samples; ++k) {
+            float4 c = sample_color[(size_t)p * rp.samples + k];
+            r += c.x; g += c.y; b += c.z;
+        }
+        float inv = 1.0f / (float)rp.samples;
+        if (radiance) { radiance[3 * p] = r * inv; radiance[3 * p + 1] = g * inv; radiance[3 * p + 2] = b * inv; }
+        float n = (float)rp.samples;
+        float fr = fminf(floorf(r / n), 255.0f), fg = fminf(floorf(g / n), 255.0f), fb = fminf(floorf(b / n), 255.0f);
+        bgr[3 * p] = (uint8_t)fb; bgr[3 * p + 1] = (uint8_t)fg; bgr[3 * p + 2] = (uint8_t)fr;
+    }
+}
+
+// closest hits for arbitrary rays (t3d_closest_hits)
+__global__ __launch_bounds__(T3D_BLOCK) void k_closest(DevScene sc, const float4* __restrict__ tri_rows,
+                                                       const DevSphere* __restrict__ spheres, int n,
+                                                       const float* __restrict__ origins, const float* __restrict__ dirs,
+                                                       int lights, int back_cull, int32_t* out_obj, int32_t* out_face,
+                                                       float* out_t, int32_t* out_dir, float* out_normal) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = i < n;
+    int j = active ? i : 0;
+    V3 o = mk(origins[3 * j], origins[3 * j + 1], origins[3 * j + 2]);
+    V3 d = normalize(mk(dirs[3 * j], dirs[3 * j + 1], dirs[3 * j + 2]));
+    Hit h = closest_hit(tri_rows, sc.n_tris, spheres, sc.n_spheres, o, d, lights != 0, back_cull != 0);
+    if (!active) return;
+    int obj = -1, face = -1, dirflag = 0;
+    V3 N = mk(0, 0, 0);
+    if (h.prim >= 0) {
+        if (h.prim < sc.n_tris) {
+            int4 meta = sc.tri_meta[h.prim];
+            float4 rn = tri_rows[3 * h.prim];
+            obj = meta.x; face = meta.y; N = mk(rn.x, rn.y, rn.z);
+            dirflag = (dot(N, d) < 0.0f) ? 0 : 1;
+        } else {
+            DevSphere sp = spheres[h.prim - sc.n_tris];
+            V3 P = madd(o, d, h.t);
+            obj = sp.obj; dirflag = h.back;
+            N = normalize(mk(P.x - sp.cx, P.y - sp.cy, P.z - sp.cz));
+        }
+    }
+    out_obj[i] = obj; out_face[i] = face; out_dir[i] = dirflag;
+    out_t[i] = h.prim >= 0 ? h.t : __builtin_nanf("");
+    if (out_normal) { out_normal[3 * i] = N.x; out_normal[3 * i + 1] = N.y; out_normal[3 * i + 2] = N.z; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct t3d_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::string err;
+    bool has_scene = false;
+    int n_sm = 256;
+    // scene buffers
+    DevScene sc{};
+    void* d_tri_rows = nullptr; void* d_tri_meta = nullptr; void* d_spheres = nullptr; void* d_lights = nullptr;
+    void* d_shaders = nullptr; void* d_obj_ior = nullptr;
+    int n_objects = 0, n_sphere_objs = 0, n_light_objs = 0;
+    // work buffers
+    size_t cap_alloc = 0; int levels_alloc = 0;
+    RayRec* d_rays[2] = {nullptr, nullptr};
+    NodePool pool{};
+    size_t n0_alloc = 0;
+    float4* d_sample_color = nullptr;
+    Counters* d_cnt = nullptr;
+    Counters* h_cnt = nullptr;  // pinned
+    // staging for host outputs
+    size_t out_alloc = 0;
+    uint8_t* d_bgr = nullptr; float* d_rad = nullptr; int32_t* d_prim = nullptr; float* d_prim_t = nullptr;
+    size_t mem_budget = (size_t)48 << 30;
+};
+
+static thread_local std::string g_create_err;
+
+#define HIPCHK(ctx, call)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                            \
+            return T3D_E_DEVICE;                                                                       \
+        }                                                                                              \
+    } while (0)
+
+extern "C" int t3d_abi_version(void) { return T3D_ABI_VERSION; }
+
+extern "C" int t3d_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return T3D_E_DEVICE;
+    return n;
+}
+
+extern "C" const char* t3d_last_error(const t3d_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int t3d_create(int device, t3d_ctx** out) {
+    if (!out) return T3D_E_INVALID;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { g_create_err = "no HIP device visible"; return T3D_E_DEVICE; }
+    if (device < 0 || device >= n) { g_create_err = "device index out of range"; return T3D_E_INVALID; }
+    t3d_ctx* c = new t3d_ctx();
+    c->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+        g_create_err = std::string("t3d_create: ") + hipGetErrorString(e);
+        delete c;
+        return T3D_E_DEVICE;
+    }
+    for (auto& ev : c->ev) hipEventCreate(&ev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_sm = prop.multiProcessorCount;
+    if (hipMalloc((void**)&c->d_cnt, sizeof(Counters)) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_cnt, sizeof(Counters), hipHostMallocDefault) != hipSuccess) {
+        g_create_err = "t3d_create: counter allocation failed";
+        delete c;
+        return T3D_E_NOMEM;
+    }
+    *out = c;
+    return T3D_OK;
+}
+
+static void free_scene(t3d_ctx* c) {
+    hipFree(c->d_tri_rows); hipFree(c->d_tri_meta); hipFree(c->d_spheres); hipFree(c->d_lights);
+    hipFree(c->d_shaders); hipFree(c->d_obj_ior);
+    c->d_tri_rows = c->d_tri_meta = c->d_spheres = c->d_lights = c->d_shaders = c->d_obj_ior = nullptr;
+    c->has_scene = false;
+}
+static void free_work(t3d_ctx* c) {
+    hipFree(c->d_rays[0]); hipFree(c->d_rays[1]); hipFree(c->pool.a); hipFree(c->pool.b); hipFree(c->pool.c);
+    hipFree(c->pool.d); hipFree(c->pool.dbg);
+    c->d_rays[0] = c->d_rays[1] = nullptr; c->pool = NodePool{}; c->cap_alloc = 0; c->levels_alloc = 0;
+}
+
+extern "C" void t3d_destroy(t3d_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    free_scene(c); free_work(c);
+    hipFree(c->d_sample_color); hipFree(c->d_cnt); hipHostFree(c->h_cnt);
+    hipFree(c->d_bgr); hipFree(c->d_rad); hipFree(c->d_prim); hipFree(c->d_prim_t);
+    for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+template <typename T>
+static int upload(t3d_ctx* c, void** dst, const std::vector<T>& v) {
+    size_t bytes = sizeof(T) * (v.empty() ? 1 : v.size());
+    HIPCHK(c, hipMalloc(dst, bytes));
+    if (!v.empty()) HIPCHK(c, hipMemcpy(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+    return T3D_OK;
+}
+
+extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
+    if (!c) return T3D_E_INVALID;
+    if (!s || s->n_objects < 0 || s->n_tris < 0 || s->n_shaders < 0 || s->n_lights < 0) { c->err = "t3d_upload_scene: bad description"; return T3D_E_INVALID; }
+    if (s->n_lights > T3D_MAX_LIGHTS) { c->err = "t3d_upload_scene: too many lights (limit 64)"; return T3D_E_CAPACITY; }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_scene(c);
+
+    std::vector<float4> rows((size_t)3 * s->n_tris);
+    std::vector<int4> meta((size_t)s->n_tris);
+    std::vector<DevSphere> spheres;
+    std::vector<float> obj_ior((size_t)s->n_objects);
+    c->n_sphere_objs = c->n_light_objs = 0;
+    for (int o = 0; o < s->n_objects; ++o) {
+        obj_ior[o] = (float)s->obj_ior[o];
+        int ty = s->obj_type[o];
+        if (ty == T3D_OBJ_MESH) {
+            int b0 = s->obj_tri_begin[o], n = s->obj_tri_count[o];
+            if (b0 < 0 || n < 0 || b0 + n > s->n_tris) { c->err = "t3d_upload_scene: triangle range out of bounds"; return T3D_E_INVALID; }
+            for (int k = 0; k < n; ++k) {
+                int t = b0 + k;
+                const double* v = s->tri_verts + 9 * (size_t)t;
+                double e1[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]}, e2[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]};
+                double nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
+                double nn = nx * nx + ny * ny + nz * nz;
+                double inv = nn > 0 ? 1.0 / nn : 0.0;
+                // a = (e2 x n) / |n|^2, b = (n x e1) / |n|^2 :  P - v0 = u e1 + v e2
+                double ax = (e2[1] * nz - e2[2] * ny) * inv, ay = (e2[2] * nx - e2[0] * nz) * inv, az = (e2[0] * ny - e2[1] * nx) * inv;
+                double bx = (ny * e1[2] - nz * e1[1]) * inv, by = (nz * e1[0] - nx * e1[2]) * inv, bz = (nx * e1[1] - ny * e1[0]) * inv;
+                rows[3 * (size_t)t + 0] = make_float4((float)nx, (float)ny, (float)nz, (float)(nx * v[0] + ny * v[1] + nz * v[2]));
+                rows[3 * (size_t)t + 1] = make_float4((float)ax, (float)ay, (float)az, (float)(-(ax * v[0] + ay * v[1] + az * v[2])));
+                rows[3 * (size_t)t + 2] = make_float4((float)bx, (float)by, (float)bz, (float)(-(bx * v[0] + by * v[1] + bz * v[2])));
+                int sh = s->tri_shader[t];
+                if (sh < 0 || sh >= s->n_shaders) { c->err = "t3d_upload_scene: triangle shader index out of range"; return T3D_E_INVALID; }
+                meta[t] = make_int4(o, k, sh, 0);
+            }
+        } else if (ty == T3D_OBJ_SPHERE || ty == T3D_OBJ_LIGHT) {
+            DevSphere sp;
+            sp.cx = (float)s->obj_center[3 * o]; sp.cy = (float)s->obj_center[3 * o + 1]; sp.cz = (float)s->obj_center[3 * o + 2];
+            sp.r2 = (float)(s->obj_radius[o] * s->obj_radius[o]);
+            sp.obj = o; sp.is_light = ty == T3D_OBJ_LIGHT; sp.shader = s->obj_shader0[o];
+            sp.strength = (float)s->obj_strength[o];
+            if (sp.shader < 0 || sp.shader >= s->n_shaders) { c->err = "t3d_upload_scene: sphere/light without shader"; return T3D_E_INVALID; }
+            spheres.push_back(sp);
+            if (sp.is_light) c->n_light_objs++; else c->n_sphere_objs++;
+        }
+    }
+    std::vector<DevShader> shaders((size_t)s->n_shaders);
+    for (int k = 0; k < s->n_shaders; ++k) {
+        shaders[k] = DevShader{(float)s->shader_color[3 * k], (float)s->shader_color[3 * k + 1], (float)s->shader_color[3 * k + 2],
+                               (float)s->shader_rough[k], (float)s->shader_refl[k], (float)s->shader_emis[k], 0.f, 0.f};
+    }
+    std::vector<DevLight> lights((size_t)s->n_lights);
+    double lc[3] = {0, 0, 0};
+    for (int l = 0; l < s->n_lights; ++l) {
+        lights[l] = DevLight{(float)s->light_pos[3 * l], (float)s->light_pos[3 * l + 1], (float)s->light_pos[3 * l + 2], (float)s->light_strength[l]};
+        for (int ch = 0; ch < 3; ++ch) { lc[ch] += s->light_color[3 * l + ch] * 0.6; if (lc[ch] > 255) lc[ch] = 255; }
+    }
+    int rc;
+    if ((rc = upload(c, &c->d_tri_rows, rows)) || (rc = upload(c, &c->d_tri_meta, meta)) || (rc = upload(c, &c->d_spheres, spheres)) ||
+        (rc = upload(c, &c->d_lights, lights)) || (rc = upload(c, &c->d_shaders, shaders)) || (rc = upload(c, &c->d_obj_ior, obj_ior)))
+        return rc;
+    DevScene& d = c->sc;
+    d.n_tris = s->n_tris; d.n_spheres = (int)spheres.size(); d.n_lights = s->n_lights; d.n_shaders = s->n_shaders;
+    d.tri_rows = (const float4*)c->d_tri_rows; d.tri_meta = (const int4*)c->d_tri_meta; d.spheres = (const DevSphere*)c->d_spheres;
+    d.lights = (const DevLight*)c->d_lights; d.shaders = (const DevShader*)c->d_shaders; d.obj_ior = (const float*)c->d_obj_ior;
+    for (int k = 0; k < 3; ++k) { d.cam.pos[k] = (float)s->cam_pos[k]; d.light_color[k] = (float)lc[k]; }
+    {   // Euler.toMatrix (T3DE.py:70-94) in float64, rounded once
+        double cx = cos(s->cam_euler[0]), sx = sin(s->cam_euler[0]), cy = cos(s->cam_euler[1]), sy = sin(s->cam_euler[1]);
+        double cz = cos(s->cam_euler[2]), sz = sin(s->cam_euler[2]);
+        double m[9] = {cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx,
+                       sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx,
+                       -sy, cy * sx, cy * cx};
+        for (int k = 0; k < 9; ++k) d.cam.m[k] = (float)m[k];
+    }
+    d.cam.zlen = (float)s->cam_zlen;
+    c->n_objects = s->n_objects;
+    c->has_scene = true;
+    return T3D_OK;
+}
+
+static int ensure_work(t3d_ctx* c, size_t cap, int levels, size_t n0, bool dbg) {
+    if (cap > c->cap_alloc || levels > c->levels_alloc || (dbg && !c->pool.dbg)) {
+        free_work(c);
+        size_t cap2 = cap, lv = (size_t)levels;
+        HIPCHK(c, hipMalloc((void**)&c->d_rays[0], sizeof(RayRec) * cap2));
+        HIPCHK(c, hipMalloc((void**)&c->d_rays[1], sizeof(RayRec) * cap2));
+        HIPCHK(c, hipMalloc((void**)&c->pool.a, sizeof(float4) * cap2 * lv));
+        HIPCHK(c, hipMalloc((void**)&c->pool.b, sizeof(float4) * cap2 * lv));
+        HIPCHK(c, hipMalloc((void**)&c->pool.c, sizeof(float4) * cap2 * lv));
+        HIPCHK(c, hipMalloc((void**)&c->pool.d, sizeof(float4) * cap2 * lv));
+        if (dbg) HIPCHK(c, hipMalloc((void**)&c->pool.dbg, sizeof(int) * cap2 * lv));
+        c->cap_alloc = cap2; c->levels_alloc = levels;
+    }
+    if (n0 > c->n0_alloc) {
+        hipFree(c->d_sample_color); c->d_sample_color = nullptr; c->n0_alloc = 0;
+        HIPCHK(c, hipMalloc((void**)&c->d_sample_color, sizeof(float4) * n0));
+        c->n0_alloc = n0;
+    }
+    return T3D_OK;
+}
+
+static int check_opts(t3d_ctx* c, const t3d_opts* o, int row0, int nrows) {
+    if (!c) return T3D_E_INVALID;
+    if (!c->has_scene) { c->err = "no scene uploaded"; return T3D_E_INVALID; }
+    if (!o || o->width <= 0 || o->height <= 0 || o->bounces < 0 || o->samples < 1) { c->err = "bad options"; return T3D_E_INVALID; }
+    if (o->bounces > T3D_MAX_BOUNCES) { c->err = "bounces above the supported maximum (14)"; return T3D_E_CAPACITY; }
+    if (o->samples > 65535) { c->err = "samples above the supported maximum (65535)"; return T3D_E_CAPACITY; }
+    if (o->rng_mode != T3D_RNG_KEYED) { c->err = "the HIP library implements the keyed random mode only"; return T3D_E_INVALID; }
+    if (row0 < 0 || nrows <= 0 || row0 + nrows > o->height) { c->err = "row range outside the image"; return T3D_E_INVALID; }
+    return T3D_OK;
+}
+
+// Trace one band whose outputs are device pointers.  Returns T3D_E_CAPACITY if a level overflowed
+// its queue (the caller retries with a larger capacity factor or fewer rows).
+static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int cap_factor, uint8_t* d_bgr, float* d_rad,
+                       int32_t* d_prim, float* d_prim_t, hipStream_t st, t3d_stats* stats, const RenderParams* single,
+                       t3d_node* d_dbg, int dbg_cap) {
+    const int S = o->bounces > 1 ? o->samples : 1;  // T3DR.py:1209
+    const size_t n0 = single ? 1 : (size_t)nrows * o->width * S;
+    const int levels = o->bounces + 1;
+    size_t cap = n0 * (size_t)cap_factor;
+    if (cap < 1024) cap = 1024;
+    if (cap * (size_t)levels > (size_t)0x7FFFFFF0) { c->err = "band too large for 32-bit node indices"; return T3D_E_CAPACITY; }
+    int rc = ensure_work(c, cap, levels, n0, single != nullptr);
+    if (rc) return rc;
+
+    RenderParams rp{};
+    rp.width = o->width; rp.height = o->height; rp.row0 = row0; rp.nrows = single ? 1 : nrows;
+    rp.bounces = o->bounces; rp.samples = single ? 1 : S; rp.lights = o->lights; rp.seed = o->seed;
+    for (int k = 0; k < 3; ++k) rp.ambient[k] = (float)o->ambient[k];
+    rp.cap = (int)c->cap_alloc;
+    rp.n0 = (int)n0;
+    if (single) { rp.single = 1; rp.px0 = single->px0; rp.py0 = single->py0; rp.sample0 = single->sample0; rp.want_debug = 1; rp.width = o->width; }
+
+    HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), st));
+    TraceOut out{c->d_sample_color, d_prim, d_prim_t, d_dbg, dbg_cap};
+    const int max_blocks = c->n_sm * 8;
+    auto blocks_for = [&](size_t n) { size_t b = (n + T3D_BLOCK - 1) / T3D_BLOCK; return (int)(b < 1 ? 1 : (b > (size_t)max_blocks ? (size_t)max_blocks : b)); };
+    uint64_t launches = 0;
+    if (stats) HIPCHK(c, hipEventRecord(c->ev[0], st));
+    const float4* rows = (const float4*)c->d_tri_rows;
+    const DevSphere* sph = (const DevSphere*)c->d_spheres;
+    for (int d = 0; d < levels; ++d) {
+        RayRec* in = c->d_rays[d & 1];
+        RayRec* outq = c->d_rays[(d + 1) & 1];
+        if (d == 0)
+            hipLaunchKernelGGL(k_trace<true>, dim3(blocks_for(n0)), dim3(T3D_BLOCK), 0, st, c->sc, rows, sph, rp, d, in, outq, c->pool, c->d_cnt, out);
+        else
+            hipLaunchKernelGGL(k_trace<false>, dim3(single ? 1 : max_blocks), dim3(T3D_BLOCK), 0, st, c->sc, rows, sph, rp, d, in, outq, c->pool, c->d_cnt, out);
+        hipLaunchKernelGGL(k_shade, dim3(single ? 1 : (d == 0 ? blocks_for(n0) : max_blocks)), dim3(T3D_BLOCK), 0, st, c->sc, rows, sph, rp, d, c->pool, c->d_cnt);
+        launches += 2;
+    }
+    if (stats) HIPCHK(c, hipEventRecord(c->ev[1], st));
+    for (int d = levels - 1; d >= 0; --d) {
+        hipLaunchKernelGGL(k_resolve, dim3(single ? 1 : (d == 0 ? blocks_for(n0) : max_blocks)), dim3(T3D_BLOCK), 0, st, c->sc, rp, d, c->pool, c->d_cnt,
+                           c->d_sample_color, d_dbg, dbg_cap);
+        launches++;
+    }
+    if (!single) {
+        hipLaunchKernelGGL(k_finish, dim3(blocks_for((size_t)nrows * o->width)), dim3(T3D_BLOCK), 0, st, rp, c->d_sample_color, d_bgr, d_rad);
+        launches++;
+    }
+    if (stats) HIPCHK(c, hipEventRecord(c->ev[2], st));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
+    if (!stats && !single) return T3D_OK;  // asynchronous use: overflow is not checked
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (c->h_cnt->overflow) return T3D_E_CAPACITY;
+    if (stats) {
+        float ms_all = 0, ms_trace = 0, ms_res = 0;
+        hipEventElapsedTime(&ms_all, c->ev[0], c->ev[2]);
+        hipEventElapsedTime(&ms_trace, c->ev[0], c->ev[1]);
+        hipEventElapsedTime(&ms_res, c->ev[1], c->ev[2]);
+        uint64_t rays = 0, nodes = 0;
+        for (int d = 0; d < levels; ++d) { rays += d == 0 ? n0 : (uint64_t)c->h_cnt->n_rays[d]; nodes += (uint64_t)c->h_cnt->n_nodes[d]; }
+        uint64_t shadow = nodes * (uint64_t)c->sc.n_lights;
+        uint64_t q = rays + shadow;
+        stats->rays_api += n0 + shadow;
+        stats->queries += q;
+        stats->tri_tests += q * (uint64_t)c->sc.n_tris;
+        stats->sphere_tests += q * (uint64_t)c->sc.n_spheres - (o->lights ? 0 : n0 * (uint64_t)c->n_light_objs);
+        stats->nodes += nodes;  // shaded nodes only; emitter leaves are folded into their parents
+        stats->ms_device += ms_all; stats->ms_trace += ms_trace; stats->ms_resolve += ms_res;
+        stats->launches += launches;
+    }
+    return T3D_OK;
+}
+
+extern "C" int t3d_render_rows_device(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, uint8_t* bgr_device,
+                                      float* radiance_device, int32_t* primary_device, float* primary_t_device,
+                                      void* stream, t3d_stats* stats) {
+    int rc = check_opts(c, o, row0, nrows);
+    if (rc) return rc;
+    if (!bgr_device) { c->err = "bgr output is required"; return T3D_E_INVALID; }
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    if (stats) memset(stats, 0, sizeof *stats);
+    const int S = o->bounces > 1 ? o->samples : 1;
+    const int levels = o->bounces + 1;
+    // rows per band: the optimistic working set (capacity factor 2 per level) must fit the budget
+    const size_t per_sample = (size_t)2 * (2 * sizeof(RayRec) + (size_t)levels * 64) + sizeof(float4);
+    size_t max_samples = c->mem_budget / per_sample;
+    size_t max_idx = (size_t)0x7FFFFFF0 / ((size_t)levels * 2);
+    if (max_samples > max_idx) max_samples = max_idx;
+    int band = (int)(max_samples / ((size_t)o->width * S));
+    if (band < 1) band = 1;
+    if (band > nrows) band = nrows;
+    for (int r = 0; r < nrows;) {
+        int nb = band < nrows - r ? band : nrows - r;
+        size_t off = (size_t)r * o->width;
+        int factor = 2;
+        for (;;) {
+            t3d_stats band_stats{};
+            // capacity overflow can only be seen after a synchronisation; without stats the call stays asynchronous
+            rc = render_band(c, o, row0 + r, nb, factor, bgr_device + 3 * off, radiance_device ? radiance_device + 3 * off : nullptr,
+                             primary_device ? primary_device + 2 * off : nullptr, primary_t_device ? primary_t_device + off : nullptr, st,
+                             stats ? &band_stats : nullptr, nullptr, nullptr, 0);
+            if (rc == T3D_E_CAPACITY && factor < (1 << o->bounces)) {
+                size_t need = (size_t)nb * o->width * S * (size_t)factor * 2 * per_sample / 2;
+                if (need > c->mem_budget && nb > 1) { nb = (nb + 1) / 2; continue; }
+                factor *= 2;
+                continue;
+            }
+            if (rc) { if (rc == T3D_E_CAPACITY) c->err = "trace tree does not fit the node buffers"; return rc; }
+            if (stats) {
+                stats->rays_api += band_stats.rays_api; stats->queries += band_stats.queries; stats->tri_tests += band_stats.tri_tests;
+                stats->sphere_tests += band_stats.sphere_tests; stats->nodes += band_stats.nodes; stats->ms_device += band_stats.ms_device;
+                stats->ms_trace += band_stats.ms_trace; stats->ms_resolve += band_stats.ms_resolve; stats->launches += band_stats.launches;
+            }
+            break;
+        }
+        r += nb;
+    }
+    return T3D_OK;
+}
+
+extern "C" int t3d_render_rows(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, uint8_t* bgr_out, float* radiance_out,
+                               int32_t* primary_out, float* primary_t_out, t3d_stats* stats) {
+    int rc = check_opts(c, o, row0, nrows);
+    if (rc) return rc;
+    if (!bgr_out) { c->err = "bgr output is required"; return T3D_E_INVALID; }
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t npix = (size_t)nrows * o->width;
+    if (npix > c->out_alloc) {
+        hipFree(c->d_bgr); hipFree(c->d_rad); hipFree(c->d_prim); hipFree(c->d_prim_t);
+        c->d_bgr = nullptr; c->d_rad = nullptr; c->d_prim = nullptr; c->d_prim_t = nullptr; c->out_alloc = 0;
+        HIPCHK(c, hipMalloc((void**)&c->d_bgr, npix * 3));
+        HIPCHK(c, hipMalloc((void**)&c->d_rad, npix * 3 * sizeof(float)));
+        HIPCHK(c, hipMalloc((void**)&c->d_prim, npix * 2 * sizeof(int32_t)));
+        HIPCHK(c, hipMalloc((void**)&c->d_prim_t, npix * sizeof(float)));
+        c->out_alloc = npix;
+    }
+    t3d_stats local{};
+    rc = t3d_render_rows_device(c, o, row0, nrows, c->d_bgr, radiance_out ? c->d_rad : nullptr, primary_out ? c->d_prim : nullptr,
+                                primary_t_out ? c->d_prim_t : nullptr, nullptr, &local);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(bgr_out, c->d_bgr, npix * 3, hipMemcpyDeviceToHost, c->stream));
+    if (radiance_out) HIPCHK(c, hipMemcpyAsync(radiance_out, c->d_rad, npix * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (primary_out) HIPCHK(c, hipMemcpyAsync(primary_out, c->d_prim, npix * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (primary_t_out) HIPCHK(c, hipMemcpyAsync(primary_t_out, c->d_prim_t, npix * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (stats) *stats = local;
+    return T3D_OK;
+}
+
+extern "C" int t3d_trace_pixel(t3d_ctx* c, const t3d_opts* o, int x, int y, int sample, t3d_node* nodes, int capacity) {
+    int rc = check_opts(c, o, 0, 1);
+    if (rc) return rc;
+    if (!nodes || capacity <= 0 || x < 0 || y < 0 || x >= o->width || y >= o->height || sample < 0) { c->err = "t3d_trace_pixel: bad argument"; return T3D_E_INVALID; }
+    HIPCHK(c, hipSetDevice(c->device));
+    const int worst = (1 << (o->bounces + 1)) - 1;
+    const int dbg_cap = worst < 65536 ? worst : 65536;
+    t3d_node* d_dbg = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d_dbg, sizeof(t3d_node) * dbg_cap));
+    RenderParams single{};
+    single.px0 = x; single.py0 = y; single.sample0 = sample;
+    t3d_stats st{};
+    // capacity factor: a single sample can branch at every level
+    int factor = worst < 1024 ? 1 : (worst + 1023) / 1024;
+    rc = render_band(c, o, y, 1, factor, nullptr, nullptr, nullptr, nullptr, c->stream, &st, &single, d_dbg, dbg_cap);
+    int n = 0;
+    if (!rc) {
+        n = c->h_cnt->n_dbg < dbg_cap ? c->h_cnt->n_dbg : dbg_cap;
+        std::vector<t3d_node> tmp((size_t)(n > 0 ? n : 1));
+        if (n > 0 && hipMemcpy(tmp.data(), d_dbg, sizeof(t3d_node) * n, hipMemcpyDeviceToHost) != hipSuccess) { rc = T3D_E_DEVICE; c->err = "t3d_trace_pixel: copy failed"; }
+        if (!rc) {
+            // depth-first order, bounce child (2n) before transmit child (2n+1)
+            std::vector<int> order;
+            std::vector<int> stack;
+            auto find = [&](int heap) { for (int i = 0; i < n; ++i) if (tmp[i].heap == heap) return i; return -1; };
+            stack.push_back(1);
+            while (!stack.empty()) {
+                int hidx = stack.back(); stack.pop_back();
+                int i = find(hidx);
+                if (i < 0) continue;
+                order.push_back(i);
+                if (2 * hidx + 1 < 65536) { stack.push_back(2 * hidx + 1); stack.push_back(2 * hidx); }
+            }
+            int m = (int)order.size();
+            if (m > capacity) { rc = T3D_E_CAPACITY; c->err = "t3d_trace_pixel: node buffer too small"; }
+            else { for (int i = 0; i < m; ++i) nodes[i] = tmp[order[i]]; n = m; }
+        }
+    }
+    hipFree(d_dbg);
+    return rc ? rc : n;
+}
+
+extern "C" int t3d_closest_hits(t3d_ctx* c, int n, const float* origins, const float* dirs, int lights, int back_cull,
+                                int32_t* out_obj, int32_t* out_face, float* out_t, int32_t* out_dirflag, float* out_normal) {
+    if (!c) return T3D_E_INVALID;
+    if (!c->has_scene) { c->err = "no scene uploaded"; return T3D_E_INVALID; }
+    if (n < 0 || !origins || !dirs || !out_obj || !out_face || !out_t || !out_dirflag) { c->err = "t3d_closest_hits: bad argument"; return T3D_E_INVALID; }
+    if (n == 0) return T3D_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr, *d_n = nullptr;
+    int32_t *d_obj = nullptr, *d_face = nullptr, *d_dir = nullptr;
+    size_t n3 = (size_t)n * 3 * sizeof(float);
+    int rc = T3D_OK;
+    auto cleanup = [&]() { hipFree(d_o); hipFree(d_d); hipFree(d_t); hipFree(d_n); hipFree(d_obj); hipFree(d_face); hipFree(d_dir); };
+#define CH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { c->err = std::string(#call) + ": " + hipGetErrorString(e_); cleanup(); return T3D_E_DEVICE; } } while (0)
+    CH(hipMalloc((void**)&d_o, n3)); CH(hipMalloc((void**)&d_d, n3)); CH(hipMalloc((void**)&d_t, n * sizeof(float))); CH(hipMalloc((void**)&d_n, n3));
+    CH(hipMalloc((void**)&d_obj, n * sizeof(int32_t))); CH(hipMalloc((void**)&d_face, n * sizeof(int32_t))); CH(hipMalloc((void**)&d_dir, n * sizeof(int32_t)));
+    CH(hipMemcpyAsync(d_o, origins, n3, hipMemcpyHostToDevice, c->stream));
+    CH(hipMemcpyAsync(d_d, dirs, n3, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_closest, dim3((n + T3D_BLOCK - 1) / T3D_BLOCK), dim3(T3D_BLOCK), 0, c->stream, c->sc, (const float4*)c->d_tri_rows,
+                       (const DevSphere*)c->d_spheres, n, d_o, d_d, lights, back_cull, d_obj, d_face, d_t, d_dir, d_n);
+    CH(hipGetLastError());
+    CH(hipMemcpyAsync(out_obj, d_obj, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    CH(hipMemcpyAsync(out_face, d_face, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    CH(hipMemcpyAsync(out_t, d_t, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    CH(hipMemcpyAsync(out_dirflag, d_dir, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (out_normal) CH(hipMemcpyAsync(out_normal, d_n, n3, hipMemcpyDeviceToHost, c->stream));
+    CH(hipStreamSynchronize(c->stream));
+#undef CH
+    cleanup();
+    return rc;
+}
