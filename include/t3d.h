@@ -85,21 +85,28 @@ typedef struct t3d_opts {
     uint32_t seed;
     int32_t use_bvh;    /* options['bvh'];  results do not depend on it (conservative culling)     */
     int32_t use_aabb;   /* options['aabb']; likewise                                               */
-    int32_t reserved;
+    int32_t row_stride; /* local row k of a render call is image row row0 + k * row_stride; 0 means 1  */
     double ambient[3];  /* options['ambient'] r,g,b                                                */
 } t3d_opts;
 
+#define T3D_STATS_N_COUNTERS 11
 typedef struct t3d_stats {
-    uint64_t rays_api;     /* Rendered.rays: primary samples + shadow rays (T3DR.py:842, 1211)      */
-    uint64_t queries;      /* closest-hit queries: primary + bounce + transmit + shadow             */
-    uint64_t tri_tests;    /* ray-triangle tests executed                                           */
-    uint64_t sphere_tests; /* ray-sphere tests executed                                             */
-    uint64_t aabb_tests;   /* ray-box tests executed                                                */
-    uint64_t nodes;        /* trace-tree nodes created (hits)                                       */
-    double ms_device;      /* device time of the whole call, HIP events on the library's stream     */
-    double ms_trace;       /* of which: closest-hit kernels (trace + shadow)                        */
-    double ms_resolve;     /* of which: colour resolve + image store                                */
-    uint64_t launches;     /* kernel launches issued                                                */
+    /* T3D_STATS_N_COUNTERS integer counters first, then the timings */
+    uint64_t rays_api;       /* Rendered.rays: primary samples + shadow rays (T3DR.py:842, 1211)     */
+    uint64_t queries;        /* closest-hit queries: primary + bounce + transmit + shadow            */
+    uint64_t trace_queries;  /* of which traced by k_trace (primary, bounce, transmit)                */
+    uint64_t shadow_queries; /* of which traced by k_shade (one per light per shaded node)           */
+    uint64_t tri_tests;      /* ray-triangle tests executed                                          */
+    uint64_t sphere_tests;   /* ray-sphere tests executed                                            */
+    uint64_t aabb_tests;     /* ray-box tests executed                                               */
+    uint64_t nodes;          /* shaded trace-tree nodes (emitter leaves are folded into the parent)  */
+    uint64_t launches;       /* kernel launches issued                                               */
+    uint64_t n_k_trace;      /* launches of k_trace                                                  */
+    uint64_t n_k_shade;      /* launches of k_shade                                                  */
+    double ms_device;        /* device time of the whole call (HIP events on the launch stream)      */
+    double ms_k_trace;       /* sum of k_trace launch durations                                      */
+    double ms_k_shade;       /* sum of k_shade launch durations                                      */
+    double ms_resolve;       /* colour resolve + image store                                         */
 } t3d_stats;
 
 /* One trace-tree node as t3d_trace_pixel returns it (TraceTreeNode, T3DE.py:273-280). */
@@ -136,7 +143,8 @@ const char* t3d_last_error(const t3d_ctx* ctx); /* ctx may be NULL: error of a f
 int t3d_upload_scene(t3d_ctx* ctx, const t3d_scene_desc* scene);
 
 /*
- * Render image rows [row0, row0+nrows): Photon.renderStripe (T3DR.py:1183-1242) with everything
+ * Render nrows image rows starting at row0 (consecutive, or every opts->row_stride-th row for
+ * interleaved multi-GPU tiles): Photon.renderStripe (T3DR.py:1183-1242) with everything
  * under it (pixelToVector, getRay, trace, computeColor, getDirectLight, getFirstCollision).
  *   bgr_out       [nrows*W*3] uint8, B,G,R per pixel like the stripe array (T3DR.py:1219-1221)
  *   radiance_out  [nrows*W*3] float, mean sample colour before the floor (nullable)

@@ -63,12 +63,12 @@ def _p(arr, ctype):
 
 
 def render(flat: FlatScene, options: dict, seed=0, rng_mode=0, row0=0, nrows=None, want_nodes=False,
-           want_radiance=True, want_fragility=False, node_cap=None):
+           want_radiance=True, want_fragility=False, node_cap=None, row_stride=1):
     """Render rows with the oracle.  Returns a dict: bgr, rgb, radiance, prim (obj, face), prim_t,
     stats, nodes (structured array) ..."""
-    opts = make_opts(options, seed, rng_mode)
+    opts = make_opts(options, seed, rng_mode, row_stride)
     W, H = opts.width, opts.height
-    nrows = H - row0 if nrows is None else nrows
+    nrows = (H - row0 + row_stride - 1) // row_stride if nrows is None else nrows
     desc = flat.as_desc()
     bgr = np.zeros((nrows, W, 3), np.uint8)
     rad = np.zeros((nrows, W, 3), np.float64) if want_radiance else None

@@ -504,6 +504,7 @@ typedef struct Node { Ray ray; Collision ci; struct Node *left, *right; int heap
 static void free_tree(Node* n) { if (!n) return; free_tree(n->left); free_tree(n->right); free(n); }
 
 static Node* trace(Ctx* c, const Ray* ray, int bounces, int lights, int heap) {
+    c->st.trace_queries++;
     Collision ci = first_collision(c, ray, lights, ray->ior == 1);
     if (ci.obj < 0) return NULL;
     c->st.nodes++;
@@ -553,6 +554,7 @@ static RGBd shader_color(const t3d_scene_desc* s, int sh) {
 
 static double visibility(Ctx* c, const Ray* ray) {
     const t3d_scene_desc* s = c->s;
+    c->st.shadow_queries++;
     Collision ci = first_collision(c, ray, 1, 0);
     if (ci.obj >= 0 && s->obj_type[ci.obj] != T3D_OBJ_LIGHT) {
         int sh = get_shader(s, ci.obj, ci.face);
@@ -718,9 +720,10 @@ int t3do_render_rows(const t3d_scene_desc* s, const t3d_opts* o, int row0, int n
     int W = o->width;
     int nsamp = o->bounces > 1 ? o->samples : 1;
     RGBd* samples = (RGBd*)malloc(sizeof(RGBd) * (nsamp > 0 ? nsamp : 1));
+    const int rstride = o->row_stride > 1 ? o->row_stride : 1;
     for (int y = 0; y < nrows; y++)
         for (int x = 0; x < W; x++) {
-            int py = row0 + y;
+            int py = row0 + y * rstride;
             Ray ray = camera_ray(s, o, x, py);
             c.kx = (uint32_t)x; c.ky = (uint32_t)py;
             size_t pix = (size_t)y * W + x;
@@ -771,7 +774,7 @@ int t3do_primary_fragility(const t3d_scene_desc* s, const t3d_opts* o, int row0,
     int W = o->width;
     for (int y = 0; y < nrows; y++)
         for (int x = 0; x < W; x++) {
-            Ray ray = camera_ray(s, o, x, row0 + y);
+            Ray ray = camera_ray(s, o, x, row0 + y * (o->row_stride > 1 ? o->row_stride : 1));
             c.frag = INFINITY;
             (void)first_collision(&c, &ray, o->lights, 1);
             frag_out[(size_t)y * W + x] = c.frag;

@@ -123,11 +123,11 @@ class Context:
         self.flat = flat
 
     def render_rows(self, options: dict, seed: int = 0, row0: int = 0, nrows: int | None = None,
-                    want_radiance=False, want_primary=False):
+                    want_radiance=False, want_primary=False, row_stride: int = 1):
         """-> dict(bgr uint8 [rows,W,3], radiance, prim [rows,W,2], prim_t, stats dict)"""
-        opts = make_opts(options, seed)
+        opts = make_opts(options, seed, row_stride=row_stride)
         W = opts.width
-        nrows = opts.height - row0 if nrows is None else nrows
+        nrows = (opts.height - row0 + row_stride - 1) // row_stride if nrows is None else nrows
         bgr = np.empty((nrows, W, 3), np.uint8)
         rad = np.empty((nrows, W, 3), np.float32) if want_radiance else None
         prim = np.empty((nrows, W, 2), np.int32) if want_primary else None
@@ -138,9 +138,10 @@ class Context:
         return dict(bgr=bgr, radiance=rad, prim=prim, prim_t=prim_t, stats=stats.as_dict())
 
     def render_rows_device(self, options: dict, seed: int, row0: int, nrows: int, bgr_ptr: int, radiance_ptr: int = 0,
-                           primary_ptr: int = 0, primary_t_ptr: int = 0, stream: int = 0, want_stats=True):
+                           primary_ptr: int = 0, primary_t_ptr: int = 0, stream: int = 0, want_stats=True,
+                           row_stride: int = 1):
         """Outputs go to caller-owned device memory (raw addresses, e.g. ``tensor.data_ptr()``)."""
-        opts = make_opts(options, seed)
+        opts = make_opts(options, seed, row_stride=row_stride)
         stats = Stats() if want_stats else None
         self._check(self._lib.t3d_render_rows_device(
             self._h, C.byref(opts), row0, nrows, C.c_void_p(bgr_ptr), C.c_void_p(radiance_ptr or None),

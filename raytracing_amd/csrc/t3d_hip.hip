@@ -79,7 +79,7 @@ struct DevScene {
 };
 
 struct RenderParams {
-    int width, height, row0, nrows;
+    int width, height, row0, nrows, row_stride;
     int bounces, samples, lights;
     uint32_t seed;
     float ambient[3];
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_trace(DevScene sc, const float4* 
                 smp = i - pix * rp.samples;
                 int ly = pix / rp.width;
                 px = pix - ly * rp.width;
-                py = rp.row0 + ly;
+                py = rp.row0 + ly * rp.row_stride;
                 if (rp.single) { px = rp.px0; py = rp.py0; smp = rp.sample0; }
                 camera_ray(sc.cam, rp, px, py, o, d);
                 parent = i;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_trace(DevScene sc, const float4* 
                 smp = (int)ps - pix * rp.samples;
                 int ly = pix / rp.width;
                 px = pix - ly * rp.width;
-                py = rp.row0 + ly;
+                py = rp.row0 + ly * rp.row_stride;
                 if (rp.single) { px = rp.px0; py = rp.py0; smp = rp.sample0; }
             }
         }
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_closest(DevScene sc, const float4
 struct t3d_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[2 * (T3D_MAX_BOUNCES + 1) + 4] = {};
     std::string err;
     bool has_scene = false;
     int n_sm = 256;
@@ -812,7 +812,10 @@ static int check_opts(t3d_ctx* c, const t3d_opts* o, int row0, int nrows) {
     if (o->bounces > T3D_MAX_BOUNCES) { c->err = "bounces above the supported maximum (14)"; return T3D_E_CAPACITY; }
     if (o->samples > 65535) { c->err = "samples above the supported maximum (65535)"; return T3D_E_CAPACITY; }
     if (o->rng_mode != T3D_RNG_KEYED) { c->err = "the HIP library implements the keyed random mode only"; return T3D_E_INVALID; }
-    if (row0 < 0 || nrows <= 0 || row0 + nrows > o->height) { c->err = "row range outside the image"; return T3D_E_INVALID; }
+    {
+        long stride = o->row_stride > 1 ? o->row_stride : 1;
+        if (row0 < 0 || nrows <= 0 || row0 + (long)(nrows - 1) * stride >= o->height) { c->err = "row range outside the image"; return T3D_E_INVALID; }
+    }
     return T3D_OK;
 }
 
@@ -832,6 +835,7 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
 
     RenderParams rp{};
     rp.width = o->width; rp.height = o->height; rp.row0 = row0; rp.nrows = single ? 1 : nrows;
+    rp.row_stride = o->row_stride > 1 ? o->row_stride : 1;
     rp.bounces = o->bounces; rp.samples = single ? 1 : S; rp.lights = o->lights; rp.seed = o->seed;
     for (int k = 0; k < 3; ++k) rp.ambient[k] = (float)o->ambient[k];
     rp.cap = (int)c->cap_alloc;
@@ -843,9 +847,12 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
     const int max_blocks = c->n_sm * 8;
     auto blocks_for = [&](size_t n) { size_t b = (n + T3D_BLOCK - 1) / T3D_BLOCK; return (int)(b < 1 ? 1 : (b > (size_t)max_blocks ? (size_t)max_blocks : b)); };
     uint64_t launches = 0;
-    if (stats) HIPCHK(c, hipEventRecord(c->ev[0], st));
+    // per-launch timing (only when the caller asked for stats): event 2k before, 2k+1 after closest-hit launch k
+    int n_timed = 0;
+    auto tick = [&]() -> hipError_t { return stats ? hipEventRecord(c->ev[n_timed++], st) : hipSuccess; };
     const float4* rows = (const float4*)c->d_tri_rows;
     const DevSphere* sph = (const DevSphere*)c->d_spheres;
+    HIPCHK(c, tick());  // ev[0]: start of the call
     for (int d = 0; d < levels; ++d) {
         RayRec* in = c->d_rays[d & 1];
         RayRec* outq = c->d_rays[(d + 1) & 1];
@@ -853,10 +860,11 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
             hipLaunchKernelGGL(k_trace<true>, dim3(blocks_for(n0)), dim3(T3D_BLOCK), 0, st, c->sc, rows, sph, rp, d, in, outq, c->pool, c->d_cnt, out);
         else
             hipLaunchKernelGGL(k_trace<false>, dim3(single ? 1 : max_blocks), dim3(T3D_BLOCK), 0, st, c->sc, rows, sph, rp, d, in, outq, c->pool, c->d_cnt, out);
+        HIPCHK(c, tick());  // ev[1 + 2d]: k_trace(d) done
         hipLaunchKernelGGL(k_shade, dim3(single ? 1 : (d == 0 ? blocks_for(n0) : max_blocks)), dim3(T3D_BLOCK), 0, st, c->sc, rows, sph, rp, d, c->pool, c->d_cnt);
+        HIPCHK(c, tick());  // ev[2 + 2d]: k_shade(d) done
         launches += 2;
     }
-    if (stats) HIPCHK(c, hipEventRecord(c->ev[1], st));
     for (int d = levels - 1; d >= 0; --d) {
         hipLaunchKernelGGL(k_resolve, dim3(single ? 1 : (d == 0 ? blocks_for(n0) : max_blocks)), dim3(T3D_BLOCK), 0, st, c->sc, rp, d, c->pool, c->d_cnt,
                            c->d_sample_color, d_dbg, dbg_cap);
@@ -866,28 +874,38 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
         hipLaunchKernelGGL(k_finish, dim3(blocks_for((size_t)nrows * o->width)), dim3(T3D_BLOCK), 0, st, rp, c->d_sample_color, d_bgr, d_rad);
         launches++;
     }
-    if (stats) HIPCHK(c, hipEventRecord(c->ev[2], st));
+    HIPCHK(c, tick());  // ev[1 + 2*levels]: end of the call
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
     if (!stats && !single) return T3D_OK;  // asynchronous use: overflow is not checked
     HIPCHK(c, hipStreamSynchronize(st));
     if (c->h_cnt->overflow) return T3D_E_CAPACITY;
     if (stats) {
-        float ms_all = 0, ms_trace = 0, ms_res = 0;
-        hipEventElapsedTime(&ms_all, c->ev[0], c->ev[2]);
-        hipEventElapsedTime(&ms_trace, c->ev[0], c->ev[1]);
-        hipEventElapsedTime(&ms_res, c->ev[1], c->ev[2]);
+        float ms = 0;
+        hipEventElapsedTime(&ms, c->ev[0], c->ev[n_timed - 1]);
+        stats->ms_device += ms;
+        for (int d = 0; d < levels; ++d) {
+            hipEventElapsedTime(&ms, c->ev[2 * d], c->ev[2 * d + 1]);
+            stats->ms_k_trace += ms;
+            hipEventElapsedTime(&ms, c->ev[2 * d + 1], c->ev[2 * d + 2]);
+            stats->ms_k_shade += ms;
+        }
+        hipEventElapsedTime(&ms, c->ev[2 * levels], c->ev[n_timed - 1]);
+        stats->ms_resolve += ms;
         uint64_t rays = 0, nodes = 0;
         for (int d = 0; d < levels; ++d) { rays += d == 0 ? n0 : (uint64_t)c->h_cnt->n_rays[d]; nodes += (uint64_t)c->h_cnt->n_nodes[d]; }
         uint64_t shadow = nodes * (uint64_t)c->sc.n_lights;
         uint64_t q = rays + shadow;
         stats->rays_api += n0 + shadow;
         stats->queries += q;
+        stats->trace_queries += rays;
+        stats->shadow_queries += shadow;
         stats->tri_tests += q * (uint64_t)c->sc.n_tris;
         stats->sphere_tests += q * (uint64_t)c->sc.n_spheres - (o->lights ? 0 : n0 * (uint64_t)c->n_light_objs);
         stats->nodes += nodes;  // shaded nodes only; emitter leaves are folded into their parents
-        stats->ms_device += ms_all; stats->ms_trace += ms_trace; stats->ms_resolve += ms_res;
         stats->launches += launches;
+        stats->n_k_trace += (uint64_t)levels;
+        stats->n_k_shade += (uint64_t)levels;
     }
     return T3D_OK;
 }
@@ -918,7 +936,7 @@ extern "C" int t3d_render_rows_device(t3d_ctx* c, const t3d_opts* o, int row0, i
         for (;;) {
             t3d_stats band_stats{};
             // capacity overflow can only be seen after a synchronisation; without stats the call stays asynchronous
-            rc = render_band(c, o, row0 + r, nb, factor, bgr_device + 3 * off, radiance_device ? radiance_device + 3 * off : nullptr,
+            rc = render_band(c, o, row0 + r * (o->row_stride > 1 ? o->row_stride : 1), nb, factor, bgr_device + 3 * off, radiance_device ? radiance_device + 3 * off : nullptr,
                              primary_device ? primary_device + 2 * off : nullptr, primary_t_device ? primary_t_device + off : nullptr, st,
                              stats ? &band_stats : nullptr, nullptr, nullptr, 0);
             if (rc == T3D_E_CAPACITY && factor < (1 << o->bounces)) {
@@ -929,9 +947,10 @@ extern "C" int t3d_render_rows_device(t3d_ctx* c, const t3d_opts* o, int row0, i
             }
             if (rc) { if (rc == T3D_E_CAPACITY) c->err = "trace tree does not fit the node buffers"; return rc; }
             if (stats) {
-                stats->rays_api += band_stats.rays_api; stats->queries += band_stats.queries; stats->tri_tests += band_stats.tri_tests;
-                stats->sphere_tests += band_stats.sphere_tests; stats->nodes += band_stats.nodes; stats->ms_device += band_stats.ms_device;
-                stats->ms_trace += band_stats.ms_trace; stats->ms_resolve += band_stats.ms_resolve; stats->launches += band_stats.launches;
+                uint64_t* dst = &stats->rays_api; const uint64_t* src = &band_stats.rays_api;
+                for (int k = 0; k < T3D_STATS_N_COUNTERS; ++k) dst[k] += src[k];
+                stats->ms_device += band_stats.ms_device; stats->ms_k_trace += band_stats.ms_k_trace;
+                stats->ms_k_shade += band_stats.ms_k_shade; stats->ms_resolve += band_stats.ms_resolve;
             }
             break;
         }

@@ -46,15 +46,14 @@ class Opts(C.Structure):
     """ctypes mirror of ``t3d_opts``."""
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("bounces", C.c_int32), ("samples", C.c_int32),
                 ("lights", C.c_int32), ("rng_mode", C.c_int32), ("seed", C.c_uint32), ("use_bvh", C.c_int32),
-                ("use_aabb", C.c_int32), ("reserved", C.c_int32), ("ambient", C.c_double * 3)]
+                ("use_aabb", C.c_int32), ("row_stride", C.c_int32), ("ambient", C.c_double * 3)]
 
 
 class Stats(C.Structure):
     """ctypes mirror of ``t3d_stats``."""
-    _fields_ = [("rays_api", C.c_uint64), ("queries", C.c_uint64), ("tri_tests", C.c_uint64),
-                ("sphere_tests", C.c_uint64), ("aabb_tests", C.c_uint64), ("nodes", C.c_uint64),
-                ("ms_device", C.c_double), ("ms_trace", C.c_double), ("ms_resolve", C.c_double),
-                ("launches", C.c_uint64)]
+    _fields_ = [(n, C.c_uint64) for n in ("rays_api", "queries", "trace_queries", "shadow_queries", "tri_tests",
+                                          "sphere_tests", "aabb_tests", "nodes", "launches", "n_k_trace", "n_k_shade")] + \
+               [(n, C.c_double) for n in ("ms_device", "ms_k_trace", "ms_k_shade", "ms_resolve")]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -63,7 +62,7 @@ class Stats(C.Structure):
 RNG_KEYED, RNG_MT_SERIAL = 0, 1
 
 
-def make_opts(options: dict, seed: int = 0, rng_mode: int = RNG_KEYED) -> Opts:
+def make_opts(options: dict, seed: int = 0, rng_mode: int = RNG_KEYED, row_stride: int = 1) -> Opts:
     """Photon options dict (T3DR.py:519-525) -> ``t3d_opts``."""
     amb = options.get("ambient", (20, 20, 20))
     o = Opts()
@@ -73,6 +72,7 @@ def make_opts(options: dict, seed: int = 0, rng_mode: int = RNG_KEYED) -> Opts:
     o.rng_mode, o.seed = int(rng_mode), int(seed) & 0xFFFFFFFF
     o.use_bvh = 1 if options.get("bvh", True) else 0
     o.use_aabb = 1 if options.get("aabb", True) else 0
+    o.row_stride = int(row_stride)
     o.ambient[:] = [float(c) for c in amb]
     return o
 

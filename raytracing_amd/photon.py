@@ -1,0 +1,330 @@
+"""``Photon`` -- the ray-tracing render engine -- and ``Rendered``, its result object.
+
+Same call surface as the reference's ``T3DR`` module (T3DR.py:23-118 ``NoBoundCameraError`` /
+``Rendered``, T3DR.py:501-1242 ``Photon``, T3DR.py:1247-1267 ``ThreadsProgress``), but all tracing
+happens in the HIP library ``libt3d_hip.so`` on an MI355X; there is no CPU rendering path.
+
+Differences a caller can observe, all deliberate:
+
+* ``threads`` no longer creates Python threads.  It still has to divide ``height`` (same
+  ``ValueError``) and it is the number of stripes between which ``progressCallback`` fires and
+  ``cancelCallback`` is polled -- per stripe, not per pixel.
+* random directions for bounce()/transmit() come from the keyed generator in ``keyed_rng`` (option
+  ``seed``, default 0), so an image is reproducible and independent of how rows are split.
+* ``Rendered.traces`` is a lazy mapping: ``traces[(x, y)]`` re-traces that pixel on the GPU.
+* extra option keys: ``device`` (HIP device index, default 0), ``seed``.
+"""
+from __future__ import annotations
+
+import copy
+import json
+import threading
+import time as _time
+from collections.abc import Mapping
+
+import numpy as np
+
+from . import _native
+from .flatten import flatten_scene
+from .scene import RGB, Ray, Scale, TraceTreeNode, Vec3
+
+
+class NoBoundCameraError(Exception):
+    def __init__(self, message="Scene contains no bound camera. Bind a camera in order to render.\n\n"
+                               "\t\tScene().camera = Camera()\n\n\tOR\tcamera = Camera(Scene())\n\n"):
+        self.message = message
+        super().__init__(self.message)
+
+
+class ThreadsProgress:
+    """Lock-guarded progress table; every update calls ``callback(table, key, total)``
+    (T3DR.py:1247-1267)."""
+
+    def __init__(self, callback, total):
+        self.lock = threading.Lock()
+        self.total = total
+        self.callback = callback
+        self._table = {}
+
+    def __getitem__(self, key):
+        with self.lock:
+            return self._table[key]
+
+    def __setitem__(self, key, value):
+        with self.lock:
+            self._table[key] = value
+            self.callback(self._table, key, self.total)
+
+
+class LazyTraces(Mapping):
+    """``{(x, y): [TraceTreeNode | None per sample]}`` computed on demand by re-tracing the pixel."""
+
+    def __init__(self, photon, width, height, samples, options, seed):
+        self._photon, self._w, self._h, self._s = photon, width, height, samples
+        self._options, self._seed = dict(options), seed
+        self._cache = {}
+
+    def __len__(self):
+        return self._w * self._h
+
+    def __iter__(self):
+        return ((x, y) for y in range(self._h) for x in range(self._w))
+
+    def __contains__(self, key):
+        return (isinstance(key, tuple) and len(key) == 2 and 0 <= key[0] < self._w and 0 <= key[1] < self._h)
+
+    def __getitem__(self, key):
+        if key not in self:
+            raise KeyError(key)
+        if key not in self._cache:
+            self._cache[key] = [self._photon._trace_pixel_tree(self._options, key[0], key[1], s, self._seed)
+                                for s in range(self._s)]
+        return self._cache[key]
+
+
+class Rendered:
+    """A finished image plus how it was made (T3DR.py:30-118).  ``imgData`` is RGB uint8 [H, W, 3]."""
+
+    def __init__(self, imgData, traces, width, height, time=None, rays=None, options=None, failed=False, engine=None):
+        self.imgData = np.flip(np.asarray(imgData), 2)  # callers hand over BGR
+        self.traces = traces
+        self.width = width
+        self.height = height
+        self.time = time
+        self.rays = rays
+        self.options = options
+        self.failed = failed
+        self.engine = engine
+        self.stats = None
+
+    def imageAs(self, type):
+        if type == "np":
+            return self.imgData
+        if type == "cv2":
+            return np.flip(self.imgData, 2)
+        if type in ("listList", "list"):
+            return self.imgData.astype(int).tolist()
+        if type == "tupleList":
+            return [[tuple(int(c) for c in pix) for pix in row] for row in self.imgData]
+        return None
+
+    def toDict(self, includeTraces=False):
+        options = dict(self.options or {})
+        if "ambient" in options:
+            options["ambient"] = [*options["ambient"]]
+        traces = {}
+        if includeTraces:
+            traces = {f"{x},{y}": [t.toDict() if t is not None else None for t in per_pixel]
+                      for (x, y), per_pixel in self.traces.items()}
+        return {"imgData": self.imageAs("listList"), "traces": traces, "width": self.width, "height": self.height,
+                "time": self.time, "rays": self.rays, "options": options, "failed": self.failed, "engine": self.engine}
+
+    @staticmethod
+    def fromDict(data):
+        options = data.get("options", {})
+        if "ambient" in options:
+            options["ambient"] = RGB(*options["ambient"])
+        rgb = np.asarray(data.get("imgData", []), dtype=np.uint8).reshape(-1, max(1, data.get("width", 1440)), 3)
+        traces = {tuple(int(v) for v in key.split(",")): [TraceTreeNode.fromDict(t) if t is not None else None for t in per_pixel]
+                  for key, per_pixel in data.get("traces", {}).items()}
+        return Rendered(np.flip(rgb, 2), traces, data.get("width", 1440), data.get("height", 900), data.get("time", 0),
+                        data.get("rays", 0), options, failed=data.get("failed", False), engine=data.get("engine", "debug"))
+
+    def saveJSON(self, filepath):
+        with open(filepath, "w") as f:
+            json.dump(self.toDict(), f)
+
+    @staticmethod
+    def fromJSON(filepath):
+        with open(filepath, "r") as f:
+            return Rendered.fromDict(json.load(f))
+
+
+_DEFAULTS = {"debug": False, "bounces": 1, "wait": True, "samples": 1, "bvh": True, "debugOptions": None,
+             "aabb": True, "lights": True, "transformBefore": True, "threads": 4, "width": 1440, "height": 900}
+
+
+class Photon:
+    """Ray tracer.  ``Photon(scene, options).render()`` -> ``Rendered``."""
+
+    def __init__(self, scene, options=None):
+        self._ctx = None
+        self._flat = None
+        self._baked = None
+        self.scene = scene
+        self.options = self.mergeDefaultOptions({} if options is None else options)
+        self.rays = 0
+
+    # -- scene / options -----------------------------------------------------------------------
+    @property
+    def scene(self):
+        return self._scene
+
+    @scene.setter
+    def scene(self, scene):
+        self._scene = scene
+        self._flat = None
+        self._baked = None
+
+    @property
+    def transformedScene(self):
+        """Deep copy of the scene with mesh transforms baked in (T3DR.py:1090-1100), made on first
+        use; before any render it is the scene itself, as in the reference (T3DR.py:504)."""
+        if self._baked is None:
+            return self._scene
+        if self._baked is True:
+            baked = copy.deepcopy(self._scene)
+            for obj in baked.objects:
+                if obj.type == "mesh":
+                    obj.setTransforms()
+            self._baked = baked
+        return self._baked
+
+    @transformedScene.setter
+    def transformedScene(self, scene):
+        self._baked = scene
+
+    def mergeDefaultOptions(self, options):
+        """Fill the missing keys of ``options`` in place (T3DR.py:519-525)."""
+        for key, value in _DEFAULTS.items():
+            if key not in options:
+                options[key] = {} if key == "debugOptions" else value
+        if "ambient" not in options:
+            options["ambient"] = RGB(20, 20, 20)
+        return options
+
+    def _camera_scene(self):
+        return self.transformedScene if self.options["transformBefore"] else self._scene
+
+    def _context(self):
+        if self._ctx is None:
+            self._ctx = _native.Context(int(self.options.get("device", 0)))
+        return self._ctx
+
+    def _prepare(self, force=False):
+        """Flatten the scene and upload it.  Live-edited scenes (``transformBefore`` False, the
+        picking path of explorer.py:324-355) are re-flattened on every call."""
+        if self._scene.camera is None:
+            raise NoBoundCameraError()
+        if force or self._flat is None or not self.options["transformBefore"]:
+            self._flat = flatten_scene(self._scene)
+            self._context().upload(self._flat)
+        return self._context()
+
+    def _native_options(self):
+        o = self.options
+        return {"width": o["width"], "height": o["height"], "bounces": o["bounces"], "samples": o["samples"],
+                "lights": o["lights"], "bvh": o["bvh"], "aabb": o["aabb"], "ambient": tuple(o["ambient"])}
+
+    # -- camera (T3DR.py:528-551) ----------------------------------------------------------------
+    def pixelToVector(self, pixelX, pixelY) -> Vec3:
+        camera = self._camera_scene().camera
+        width, height = self.options["width"], self.options["height"]
+        ratio = width / height
+        local = Vec3((pixelX / width) * ratio - ratio / 2, 0.5 - pixelY / height, camera.length / 20)
+        return local.applyTransforms(camera.position, Scale(1, 1, 1), camera.rotation)
+
+    def getRay(self, pixelVec) -> Ray:
+        start = self._camera_scene().camera.position
+        return Ray(start, (pixelVec - start).normalise(), 1, None)
+
+    # -- single queries ----------------------------------------------------------------------------
+    def getFirstCollision(self, ray, lights, backCull=True):
+        """Closest hit of one ray (T3DR.py:654-730); dict with None entries for a miss."""
+        ctx = self._prepare()
+        hit = ctx.closest_hits([[*ray.start]], [[*ray.direction]], lights, backCull)
+        oi = int(hit["obj"][0])
+        if oi < 0:
+            return {"object": None, "point": None, "t": None, "normal": None, "direction": None, "face": None}
+        obj = self._camera_scene().objects[oi]
+        t = float(hit["t"][0])
+        fi = int(hit["face"][0])
+        return {"object": obj, "point": ray.pointOnRay(t), "t": t, "normal": Vec3(*(float(c) for c in hit["normal"][0])),
+                "direction": int(hit["direction"][0]), "face": obj.mesh.faces[fi] if fi >= 0 else None}
+
+    def getAttenuation(self, distance, k=0.01) -> float:
+        return max(0, min(1, 1 / (1 + k * distance ** 2)))
+
+    def getAllLightsPos(self):
+        """``[[position, strength, colour], ...]`` in the order shading visits them (T3DR.py:789-816)."""
+        flat = self._flat if (self._flat is not None and self.options["transformBefore"]) else flatten_scene(self._scene)
+        return [[Vec3(*map(float, p)), float(s), RGB(*map(float, c))]
+                for p, s, c in zip(flat.light_pos, flat.light_strength, flat.light_color)]
+
+    def getVisibility(self, ray) -> float:
+        """1 if the first thing the ray meets is a light / emissive face (or nothing), else
+        1 - reflectivity of the blocker (T3DR.py:762-778)."""
+        hit = self.getFirstCollision(ray, True, False)
+        obj = hit["object"]
+        if obj is None or obj.type == "light":
+            return 1
+        shader = obj.getShader(hit["face"])
+        if obj.type == "mesh" and shader.emissionStrength > 0:
+            return 1
+        return 1 - shader.reflectivity
+
+    def _trace_pixel_tree(self, options, x, y, sample, seed):
+        ctx = self._prepare()
+        nodes = ctx.trace_pixel(options, x, y, sample, seed)
+        if not nodes:
+            return None
+        objects = self.transformedScene.objects
+        by_heap = {}
+        for n in nodes:
+            obj = objects[n.obj]
+            inside = objects[n.ray_obj] if n.ray_obj >= 0 else None
+            ray = Ray(Vec3(*n.ray_start), Vec3(*n.ray_dir), n.ray_ior, inside)
+            info = {"object": obj, "point": Vec3(*n.point), "t": n.t, "normal": Vec3(*n.normal),
+                    "direction": n.direction, "face": obj.mesh.faces[n.face] if n.face >= 0 else None,
+                    "color": RGB(*n.color)}
+            by_heap[n.heap] = TraceTreeNode(ray, info)
+        for heap, node in by_heap.items():
+            node.left = by_heap.get(2 * heap)
+            node.right = by_heap.get(2 * heap + 1)
+        return by_heap.get(1)
+
+    # -- render (T3DR.py:1086-1242) ------------------------------------------------------------------
+    def render(self, progressCallback=None, cancelCallback=None, returnType="rendered"):
+        if self._scene.camera is None:
+            raise NoBoundCameraError()
+        opts = self.options
+        width, height, stripes = int(opts["width"]), int(opts["height"]), int(opts["threads"])
+        if height % stripes != 0:
+            raise ValueError("Number of threads must be a factor of image height")
+        ctx = self._prepare(force=True)
+        self._baked = True  # transformedScene is rebuilt lazily from the current scene
+        native_opts = self._native_options()
+        seed = int(opts.get("seed", 0))
+        if progressCallback is None and cancelCallback is None:
+            stripes = 1
+        progressCallback = progressCallback or (lambda table, key, total: None)
+        cancelCallback = cancelCallback or (lambda: False)
+        stripe_rows = height // stripes
+        progress = ThreadsProgress(callback=progressCallback, total=stripe_rows * width)
+        self.threadsProgress = progress
+        image = np.zeros((height, width, 3), np.uint8)
+        totals = {}
+        failed = False
+        self.rays = 0
+        start = _time.time()
+        for sid in range(stripes):
+            progress[sid] = 0
+            if failed:
+                continue
+            out = ctx.render_rows(native_opts, seed=seed, row0=sid * stripe_rows, nrows=stripe_rows)
+            image[sid * stripe_rows:(sid + 1) * stripe_rows] = out["bgr"]
+            for k, v in out["stats"].items():
+                totals[k] = totals.get(k, 0) + v
+            progress[sid] = stripe_rows * width - 1
+            if cancelCallback():
+                failed = True
+        elapsed = _time.time() - start
+        rays = int(totals.get("rays_api", 0))
+        self.rays = 0
+        if returnType == "np":
+            return image
+        samples = int(opts["samples"]) if int(opts["bounces"]) > 1 else 1
+        traces = LazyTraces(self, width, height, samples, native_opts, seed)
+        rendered = Rendered(image, traces, width, height, elapsed, rays, opts, failed=failed, engine="photon")
+        rendered.stats = totals
+        return rendered
