@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s (closest-hit queries per second) and frame time, Cornell box 1920x1080,
+4 bounces, on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one complete frame: every rank traces its interleaved image rows through libt3d_hip.so
+(scene resident in HBM, output tile in HBM), then the tiles are gathered on rank 0 (RCCL).  A "ray" is
+one closest-hit query (primary + bounce + transmit + shadow).  Prints ONE JSON line on rank 0.
+
+The line also carries
+  roofline      FP32 vector-ALU roofline of the dominant kernel (k_shade, the shadow-ray closest-hit
+                kernel): algorithmic flops (51 per ray-triangle test, 19 per ray-sphere test) divided by
+                the kernel's launch durations, measured with HIP events in the last timed step
+  cpu_baseline  the float64 CPU oracle (oracle/, a restatement of the reference's algorithm) timed on this
+                host's cores on a bounded sample of the same frame (N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_TRI_TEST = 51.0     # Moeller-Trumbore with on-the-fly edges
+FLOP_PER_SPHERE_TEST = 19.0
+FP32_VALU_PEAK_TFLOPS = 157.3  # 256 CU x 128 FMA lanes x 2 flop x 2.4 GHz
+
+
+def cpu_baseline(flat, options, seed, row_step=4):
+    """Oracle timed on host threads: every `row_step`-th image row of the same frame, rows dealt
+    round-robin to the threads (ctypes releases the GIL during the C call)."""
+    from oracle import oracle
+    oracle.lib()
+    nthreads = max(1, min(16, os.cpu_count() or 1))
+    H = options["height"]
+    rows = list(range(0, H, row_step))
+    stride = row_step * nthreads
+    results = [None] * nthreads
+
+    def work(t):
+        first = t * row_step
+        if first < H:
+            results[t] = oracle.render(flat, options, seed=seed, row0=first, row_stride=stride, want_radiance=False)["stats"]
+
+    t0 = time.time()
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    dt = time.time() - t0
+    queries = sum(r["queries"] for r in results if r)
+    return {"value": queries / dt / 1e6, "unit": "Mrays/s", "cores": nthreads, "kind": "port",
+            "sample": f"{len(rows)} of {H} rows (every {row_step}th) of the same frame, {queries} queries in {dt:.2f} s",
+            "seconds": round(dt, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cornell_1080p_b4")
+    ap.add_argument("--partition", default="interleaved", choices=["interleaved", "bands"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif args.gpus != 1:
+        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+        sys.exit(2)
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    from raytracing_amd import _native
+    from raytracing_amd.flatten import flatten_scene
+    from raytracing_amd.tiles import gather_frame, partition_rows, sum_counters
+    from raytracing_amd.workloads import get_workload
+
+    scene, options = get_workload(args.workload)
+    seed = 0
+    flat = flatten_scene(scene)
+    ctx = _native.Context(local_rank)
+    ctx.upload(flat)
+    H, W = options["height"], options["width"]
+    tile = partition_rows(H, world, rank, args.partition)
+    out = torch.empty((tile.nrows, W, 3), dtype=torch.uint8, device=device)
+    stream = torch.cuda.current_stream(device).cuda_stream
+
+    def step(want_stats):
+        st = ctx.render_rows_device(options, seed, tile.row0, tile.nrows, out.data_ptr(), stream=stream,
+                                    want_stats=want_stats, row_stride=tile.stride)
+        frame = gather_frame(out, H, args.partition)
+        return st, frame
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    first_stats, frame = step(True)  # checked step: counters + capacity
+    for _ in range(max(0, args.warmup - 1)):
+        step(False)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(False)
+    sync()
+    elapsed = time.perf_counter() - t0
+    last = ctx.last_call_stats()  # kernel durations of the last timed step (HIP events on the launch stream)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    keys = ["queries", "rays_api", "tri_tests", "sphere_tests", "shadow_queries", "trace_queries", "nodes"]
+    totals = dict(zip(keys, sum_counters([first_stats[k] for k in keys], device=device)))
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = totals["queries"] * args.steps / elapsed / 1e6
+        # roofline of the dominant kernel on this rank (k_shade): algorithmic flops / measured kernel time
+        T, S = flat.n_tris, flat.n_spheres
+        flops_shade = last["shadow_queries"] * (FLOP_PER_TRI_TEST * T + FLOP_PER_SPHERE_TEST * S)
+        flops_trace = last["trace_queries"] * (FLOP_PER_TRI_TEST * T + FLOP_PER_SPHERE_TEST * S)
+        shade_s = last["ms_k_shade"] * 1e-3
+        trace_s = last["ms_k_trace"] * 1e-3
+        achieved = flops_shade / shade_s / 1e12 if shade_s > 0 else 0.0
+        line = {
+            "metric": "Mrays/s (primary+secondary closest-hit queries), Cornell 1080p 4 bounces",
+            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "width": W, "height": H, "bounces": options["bounces"],
+                       "samples": options["samples"], "triangles": T, "spheres_and_lights": S,
+                       "lights": int(len(flat.light_strength)), "partition": f"{args.partition} rows x{world}",
+                       "queries_per_frame": totals["queries"], "rendered_rays_per_frame": totals["rays_api"]},
+            "roofline": {"bound": "valu", "kernel": "k_shade", "achieved": round(achieved, 3), "peak": FP32_VALU_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4), "traffic": None,
+                         "launches_per_frame": last["n_k_shade"], "avg_launch_ms": round(last["ms_k_shade"] / max(1, last["n_k_shade"]), 5),
+                         "flops_per_frame": flops_shade,
+                         "k_trace": {"achieved": round(flops_trace / trace_s / 1e12, 3) if trace_s > 0 else 0.0,
+                                     "avg_launch_ms": round(last["ms_k_trace"] / max(1, last["n_k_trace"]), 5)},
+                         "frame_device_ms": round(last["ms_device"], 4), "resolve_ms": round(last["ms_resolve"], 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(flat, options, seed)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -185,6 +185,15 @@ int t3d_closest_hits(t3d_ctx* ctx, int n, const float* origins, const float* dir
                      int back_cull, int32_t* out_obj, int32_t* out_face, float* out_t,
                      int32_t* out_dirflag, float* out_normal);
 
+/*
+ * Counters and per-kernel timings of the most recent t3d_render_rows_device call (of its last band
+ * if the image was split into several): synchronises that call's stream first.  Lets a caller run
+ * render calls asynchronously (stats == NULL) and still read kernel durations afterwards.
+ * T3D_E_CAPACITY reports that the asynchronous call overflowed its node buffers (output invalid).
+ * No counterpart in the reference (its timing is time.time() around the threads, T3DR.py:1119-1161).
+ */
+int t3d_last_call_stats(t3d_ctx* ctx, t3d_stats* stats);
+
 int t3d_abi_version(void);
 
 #ifdef __cplusplus

@@ -96,9 +96,9 @@ def render(flat: FlatScene, options: dict, seed=0, rng_mode=0, row0=0, nrows=Non
     return out
 
 
-def primary_fragility(flat: FlatScene, options: dict, row0=0, nrows=None):
-    opts = make_opts(options)
-    nrows = opts.height - row0 if nrows is None else nrows
+def primary_fragility(flat: FlatScene, options: dict, row0=0, nrows=None, row_stride=1):
+    opts = make_opts(options, row_stride=row_stride)
+    nrows = (opts.height - row0 + row_stride - 1) // row_stride if nrows is None else nrows
     desc = flat.as_desc()
     frag = np.zeros((nrows, opts.width), np.float64)
     rc = lib().t3do_primary_fragility(C.byref(desc), C.byref(opts), row0, nrows, _p(frag, C.c_double))

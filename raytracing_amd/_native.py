@@ -16,7 +16,7 @@ ABI_VERSION = 1
 
 SYMBOLS = ("t3d_abi_version", "t3d_device_count", "t3d_create", "t3d_destroy", "t3d_last_error",
            "t3d_upload_scene", "t3d_render_rows", "t3d_render_rows_device", "t3d_trace_pixel",
-           "t3d_closest_hits")
+           "t3d_closest_hits", "t3d_last_call_stats")
 
 
 class NativeError(RuntimeError):
@@ -68,6 +68,8 @@ def load():
     lib.t3d_closest_hits.restype = C.c_int
     lib.t3d_closest_hits.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.t3d_last_call_stats.restype = C.c_int
+    lib.t3d_last_call_stats.argtypes = [C.c_void_p, P(Stats)]
     if lib.t3d_abi_version() != ABI_VERSION:
         raise NativeError(f"libt3d_hip.so has ABI version {lib.t3d_abi_version()}, expected {ABI_VERSION}")
     _lib = lib
@@ -148,6 +150,12 @@ class Context:
             C.c_void_p(primary_ptr or None), C.c_void_p(primary_t_ptr or None), C.c_void_p(stream or None),
             C.byref(stats) if stats is not None else None), "t3d_render_rows_device")
         return stats.as_dict() if stats is not None else None
+
+    def last_call_stats(self):
+        """Synchronise the most recent (possibly asynchronous) render call and return its stats."""
+        stats = Stats()
+        self._check(self._lib.t3d_last_call_stats(self._h, C.byref(stats)), "t3d_last_call_stats")
+        return stats.as_dict()
 
     def trace_pixel(self, options: dict, x: int, y: int, sample: int = 0, seed: int = 0):
         opts = make_opts(options, seed)

@@ -621,6 +621,9 @@ struct t3d_ctx {
     size_t out_alloc = 0;
     uint8_t* d_bgr = nullptr; float* d_rad = nullptr; int32_t* d_prim = nullptr; float* d_prim_t = nullptr;
     size_t mem_budget = (size_t)48 << 30;
+    // the most recent band, for t3d_last_call_stats
+    bool last_valid = false; int last_levels = 0; size_t last_n0 = 0; int last_lights = 1; uint64_t last_launches = 0;
+    hipStream_t last_stream = nullptr;
 };
 
 static thread_local std::string g_create_err;
@@ -819,6 +822,37 @@ static int check_opts(t3d_ctx* c, const t3d_opts* o, int row0, int nrows) {
     return T3D_OK;
 }
 
+// Counters and event timings of the most recent band; the stream must have been synchronised.
+static void fill_stats(t3d_ctx* c, t3d_stats* stats) {
+    const int levels = c->last_levels;
+    const int n_ev = 2 * levels + 2;
+    float ms = 0;
+    hipEventElapsedTime(&ms, c->ev[0], c->ev[n_ev - 1]);
+    stats->ms_device += ms;
+    for (int d = 0; d < levels; ++d) {
+        hipEventElapsedTime(&ms, c->ev[2 * d], c->ev[2 * d + 1]);
+        stats->ms_k_trace += ms;
+        hipEventElapsedTime(&ms, c->ev[2 * d + 1], c->ev[2 * d + 2]);
+        stats->ms_k_shade += ms;
+    }
+    hipEventElapsedTime(&ms, c->ev[2 * levels], c->ev[n_ev - 1]);
+    stats->ms_resolve += ms;
+    uint64_t rays = 0, nodes = 0;
+    for (int d = 0; d < levels; ++d) { rays += d == 0 ? c->last_n0 : (uint64_t)c->h_cnt->n_rays[d]; nodes += (uint64_t)c->h_cnt->n_nodes[d]; }
+    uint64_t shadow = nodes * (uint64_t)c->sc.n_lights;
+    uint64_t q = rays + shadow;
+    stats->rays_api += c->last_n0 + shadow;
+    stats->queries += q;
+    stats->trace_queries += rays;
+    stats->shadow_queries += shadow;
+    stats->tri_tests += q * (uint64_t)c->sc.n_tris;
+    stats->sphere_tests += q * (uint64_t)c->sc.n_spheres - (c->last_lights ? 0 : c->last_n0 * (uint64_t)c->n_light_objs);
+    stats->nodes += nodes;  // shaded nodes only; emitter leaves are folded into their parents
+    stats->launches += c->last_launches;
+    stats->n_k_trace += (uint64_t)levels;
+    stats->n_k_shade += (uint64_t)levels;
+}
+
 // Trace one band whose outputs are device pointers.  Returns T3D_E_CAPACITY if a level overflowed
 // its queue (the caller retries with a larger capacity factor or fewer rows).
 static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int cap_factor, uint8_t* d_bgr, float* d_rad,
@@ -847,9 +881,9 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
     const int max_blocks = c->n_sm * 8;
     auto blocks_for = [&](size_t n) { size_t b = (n + T3D_BLOCK - 1) / T3D_BLOCK; return (int)(b < 1 ? 1 : (b > (size_t)max_blocks ? (size_t)max_blocks : b)); };
     uint64_t launches = 0;
-    // per-launch timing (only when the caller asked for stats): event 2k before, 2k+1 after closest-hit launch k
+    // per-launch timing: event 2d+1 after k_trace(d), 2d+2 after k_shade(d); read by fill_stats
     int n_timed = 0;
-    auto tick = [&]() -> hipError_t { return stats ? hipEventRecord(c->ev[n_timed++], st) : hipSuccess; };
+    auto tick = [&]() -> hipError_t { return hipEventRecord(c->ev[n_timed++], st); };
     const float4* rows = (const float4*)c->d_tri_rows;
     const DevSphere* sph = (const DevSphere*)c->d_spheres;
     HIPCHK(c, tick());  // ev[0]: start of the call
@@ -877,36 +911,12 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
     HIPCHK(c, tick());  // ev[1 + 2*levels]: end of the call
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
+    c->last_levels = levels; c->last_n0 = n0; c->last_lights = o->lights; c->last_launches = launches; c->last_stream = st;
+    c->last_valid = true;
     if (!stats && !single) return T3D_OK;  // asynchronous use: overflow is not checked
     HIPCHK(c, hipStreamSynchronize(st));
     if (c->h_cnt->overflow) return T3D_E_CAPACITY;
-    if (stats) {
-        float ms = 0;
-        hipEventElapsedTime(&ms, c->ev[0], c->ev[n_timed - 1]);
-        stats->ms_device += ms;
-        for (int d = 0; d < levels; ++d) {
-            hipEventElapsedTime(&ms, c->ev[2 * d], c->ev[2 * d + 1]);
-            stats->ms_k_trace += ms;
-            hipEventElapsedTime(&ms, c->ev[2 * d + 1], c->ev[2 * d + 2]);
-            stats->ms_k_shade += ms;
-        }
-        hipEventElapsedTime(&ms, c->ev[2 * levels], c->ev[n_timed - 1]);
-        stats->ms_resolve += ms;
-        uint64_t rays = 0, nodes = 0;
-        for (int d = 0; d < levels; ++d) { rays += d == 0 ? n0 : (uint64_t)c->h_cnt->n_rays[d]; nodes += (uint64_t)c->h_cnt->n_nodes[d]; }
-        uint64_t shadow = nodes * (uint64_t)c->sc.n_lights;
-        uint64_t q = rays + shadow;
-        stats->rays_api += n0 + shadow;
-        stats->queries += q;
-        stats->trace_queries += rays;
-        stats->shadow_queries += shadow;
-        stats->tri_tests += q * (uint64_t)c->sc.n_tris;
-        stats->sphere_tests += q * (uint64_t)c->sc.n_spheres - (o->lights ? 0 : n0 * (uint64_t)c->n_light_objs);
-        stats->nodes += nodes;  // shaded nodes only; emitter leaves are folded into their parents
-        stats->launches += launches;
-        stats->n_k_trace += (uint64_t)levels;
-        stats->n_k_shade += (uint64_t)levels;
-    }
+    if (stats) fill_stats(c, stats);
     return T3D_OK;
 }
 
@@ -956,6 +966,17 @@ extern "C" int t3d_render_rows_device(t3d_ctx* c, const t3d_opts* o, int row0, i
         }
         r += nb;
     }
+    return T3D_OK;
+}
+
+extern "C" int t3d_last_call_stats(t3d_ctx* c, t3d_stats* stats) {
+    if (!c || !stats) return T3D_E_INVALID;
+    if (!c->last_valid) { c->err = "no render call to report on"; return T3D_E_INVALID; }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->last_stream));
+    memset(stats, 0, sizeof *stats);
+    if (c->h_cnt->overflow) { c->err = "trace tree did not fit the node buffers"; return T3D_E_CAPACITY; }
+    fill_stats(c, stats);
     return T3D_OK;
 }
 
