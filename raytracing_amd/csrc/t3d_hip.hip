@@ -37,6 +37,7 @@
 #include "../../include/t3d.h"
 
 #define T3D_BLOCK 256
+#define T3D_TRACE_BLOCK 1024 /* k_trace: one atomic per queue counter per 1024 rays */
 #define T3D_MAX_LIGHTS 64
 #define T3D_MAX_BOUNCES 14 /* heap index of the deepest node must fit 16 bits of the RNG key */
 
@@ -247,16 +248,20 @@ __device__ __forceinline__ void camera_ray(const DevCamera& cam, const RenderPar
 }
 
 template <bool LEVEL0>
-__global__ __launch_bounds__(T3D_BLOCK) void k_trace(DevScene sc, const float4* __restrict__ tri_rows,
+__global__ __launch_bounds__(T3D_TRACE_BLOCK) void k_trace(DevScene sc, const float4* __restrict__ tri_rows,
                                                      const DevSphere* __restrict__ spheres, RenderParams rp, int level,
                                                      const RayRec* __restrict__ rays_in, RayRec* __restrict__ rays_out,
                                                      NodePool pool, Counters* cnt, TraceOut out) {
     const int n = LEVEL0 ? rp.n0 : min(cnt->n_rays[level], rp.cap);
-    const int stride = gridDim.x * blockDim.x;
-    const int base_iter = (n + stride - 1) / stride;
     const size_t node_base = (size_t)level * rp.cap;
-    for (int it = 0; it < base_iter; ++it) {
-        const int i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+    // queue appends are aggregated per block: every wave ballots, wave 0 adds the block totals to the
+    // global counters with ONE atomic per counter, then each lane derives its slot from prefix counts
+    __shared__ int s_cnt[T3D_TRACE_BLOCK / 64][3];
+    __shared__ int s_base[2];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int chunk = blockIdx.x; (long long)chunk * T3D_TRACE_BLOCK < n; chunk += gridDim.x) {
+        const int i = chunk * T3D_TRACE_BLOCK + threadIdx.x;
         const bool active = i < n;
         V3 o = mk(0, 0, 0), d = mk(0, 0, 1), pstart = mk(0, 0, 0);
         float ior = 1.0f;
@@ -290,7 +295,9 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_trace(DevScene sc, const float4* 
         }
         const bool lights = LEVEL0 ? (rp.lights != 0) : true;
         const bool back_cull = (ior == 1.0f);  // T3DR.py:961
-        Hit h = closest_hit(tri_rows, sc.n_tris, spheres, sc.n_spheres, o, d, lights, back_cull);
+        Hit h;
+        h.t = 0.0f; h.prim = -1; h.back = 0;
+        if (__any(active)) h = closest_hit(tri_rows, sc.n_tris, spheres, sc.n_spheres, o, d, lights, back_cull);  // wave-uniform
         const bool hit = active && h.prim >= 0;
 
         // ---- classify ---------------------------------------------------------------------
@@ -369,27 +376,14 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_trace(DevScene sc, const float4* 
             }
         }
 
-        // ---- shaded node --------------------------------------------------------------------
+        // ---- shaded node: what it is and which children it spawns ------------------------------------
         const bool shaded = hit && !emitter;
-        int node = wave_append(&cnt->n_nodes[level], shaded);
-        bool stored = shaded && node < rp.cap;
-        if (shaded && !stored) cnt->overflow = 1;
-        if (stored) {
-            const float k = 2.0f / 255.0f;  // absent children count as ambient * 2/255 (T3DR.py:1054-1055)
-            size_t g = node_base + (size_t)node;
-            pool.a[g] = make_float4(P.x, P.y, P.z, att_parent);
-            pool.b[g] = make_float4(N.x, N.y, N.z, __int_as_float(shader | (side << 30)));
-            pool.c[g] = make_float4(rp.ambient[0] * k, rp.ambient[1] * k, rp.ambient[2] * k, __int_as_float(parent));
-            pool.d[g] = make_float4(rp.ambient[0] * k, rp.ambient[1] * k, rp.ambient[2] * k, 0.0f);
-            if (rp.want_debug) pool.dbg[g] = dbg_idx;
-        }
-
         // ---- children (T3DR.py:979-995) --------------------------------------------------------
         bool want_t = false, want_b = false;
         V3 tdir = mk(0, 0, 1), bdir = mk(0, 0, 1), tstart = P, bstart = P;
         float t_ior = 1.0f;
         int t_obj = -1;
-        if (stored && level < rp.bounces) {
+        if (shaded && level < rp.bounces) {
             DevShader sh = sc.shaders[shader];
             float refl = sh.refl, rough = sh.rough;
             if (refl != 1.0f) {
@@ -424,10 +418,36 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_trace(DevScene sc, const float4* 
                 want_b = true;
             }
         }
-        int* next_count = &cnt->n_rays[level + 1];
-        int ti = wave_append(next_count, want_t);
-        int bi = wave_append(next_count, want_b);
-        if (want_t) {
+        // ---- block-aggregated append: node slot and child-ray slots ------------------------------------
+        const unsigned long long m_n = __ballot(shaded), m_t = __ballot(want_t), m_b = __ballot(want_b);
+        if (lane == 0) { s_cnt[wid][0] = __popcll(m_n); s_cnt[wid][1] = __popcll(m_t); s_cnt[wid][2] = __popcll(m_b); }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tn = 0, tr = 0;
+            for (int w = 0; w < T3D_TRACE_BLOCK / 64; ++w) { tn += s_cnt[w][0]; tr += s_cnt[w][1] + s_cnt[w][2]; }
+            s_base[0] = tn ? atomicAdd(&cnt->n_nodes[level], tn) : 0;
+            s_base[1] = tr ? atomicAdd(&cnt->n_rays[level + 1], tr) : 0;
+        }
+        __syncthreads();
+        int node = s_base[0], rbase = s_base[1];
+        for (int w = 0; w < wid; ++w) { node += s_cnt[w][0]; rbase += s_cnt[w][1] + s_cnt[w][2]; }
+        node += __popcll(m_n & lt_mask);
+        const int ti = rbase + __popcll(m_t & lt_mask);
+        const int bi = rbase + s_cnt[wid][1] + __popcll(m_b & lt_mask);
+        __syncthreads();  // s_cnt / s_base are rewritten by the next chunk
+
+        const bool stored = shaded && node < rp.cap;
+        if (shaded && !stored) cnt->overflow = 1;
+        if (stored) {
+            const float k = 2.0f / 255.0f;  // absent children count as ambient * 2/255 (T3DR.py:1054-1055)
+            size_t g = node_base + (size_t)node;
+            pool.a[g] = make_float4(P.x, P.y, P.z, att_parent);
+            pool.b[g] = make_float4(N.x, N.y, N.z, __int_as_float(shader | (side << 30)));
+            pool.c[g] = make_float4(rp.ambient[0] * k, rp.ambient[1] * k, rp.ambient[2] * k, __int_as_float(parent));
+            pool.d[g] = make_float4(rp.ambient[0] * k, rp.ambient[1] * k, rp.ambient[2] * k, 0.0f);
+            if (rp.want_debug) pool.dbg[g] = dbg_idx;
+        }
+        if (want_t && stored) {
             if (ti < rp.cap) {
                 RayRec r;
                 r.o = make_float4(tstart.x, tstart.y, tstart.z, t_ior);
@@ -437,7 +457,7 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_trace(DevScene sc, const float4* 
                 rays_out[ti] = r;
             } else cnt->overflow = 1;
         }
-        if (want_b) {
+        if (want_b && stored) {
             if (bi < rp.cap) {
                 RayRec r;
                 r.o = make_float4(bstart.x, bstart.y, bstart.z, ior);
@@ -464,6 +484,7 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_shade(DevScene sc, const float4* 
     for (int it = 0; it < iters; ++it) {
         const int i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
         const bool active = i < n;
+        if (!__any(active)) break;  // whole wave past the end of the node list (wave-uniform)
         const size_t g = node_base + (size_t)(active ? i : 0);
         float4 a = pool.a[g], b = pool.b[g];
         V3 P = mk(a.x, a.y, a.z), N = mk(b.x, b.y, b.z);
@@ -880,6 +901,7 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
     TraceOut out{c->d_sample_color, d_prim, d_prim_t, d_dbg, dbg_cap};
     const int max_blocks = c->n_sm * 8;
     auto blocks_for = [&](size_t n) { size_t b = (n + T3D_BLOCK - 1) / T3D_BLOCK; return (int)(b < 1 ? 1 : (b > (size_t)max_blocks ? (size_t)max_blocks : b)); };
+    auto trace_blocks_for = [&](size_t n) { size_t b = (n + T3D_TRACE_BLOCK - 1) / T3D_TRACE_BLOCK; size_t mx = (size_t)c->n_sm * 2; return (int)(b < 1 ? 1 : (b > mx ? mx : b)); };
     uint64_t launches = 0;
     // per-launch timing: event 2d+1 after k_trace(d), 2d+2 after k_shade(d); read by fill_stats
     int n_timed = 0;
@@ -891,9 +913,9 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
         RayRec* in = c->d_rays[d & 1];
         RayRec* outq = c->d_rays[(d + 1) & 1];
         if (d == 0)
-            hipLaunchKernelGGL(k_trace<true>, dim3(blocks_for(n0)), dim3(T3D_BLOCK), 0, st, c->sc, rows, sph, rp, d, in, outq, c->pool, c->d_cnt, out);
+            hipLaunchKernelGGL(k_trace<true>, dim3(trace_blocks_for(n0)), dim3(T3D_TRACE_BLOCK), 0, st, c->sc, rows, sph, rp, d, in, outq, c->pool, c->d_cnt, out);
         else
-            hipLaunchKernelGGL(k_trace<false>, dim3(single ? 1 : max_blocks), dim3(T3D_BLOCK), 0, st, c->sc, rows, sph, rp, d, in, outq, c->pool, c->d_cnt, out);
+            hipLaunchKernelGGL(k_trace<false>, dim3(single ? 1 : trace_blocks_for(c->cap_alloc)), dim3(T3D_TRACE_BLOCK), 0, st, c->sc, rows, sph, rp, d, in, outq, c->pool, c->d_cnt, out);
         HIPCHK(c, tick());  // ev[1 + 2d]: k_trace(d) done
         hipLaunchKernelGGL(k_shade, dim3(single ? 1 : (d == 0 ? blocks_for(n0) : max_blocks)), dim3(T3D_BLOCK), 0, st, c->sc, rows, sph, rp, d, c->pool, c->d_cnt);
         HIPCHK(c, tick());  // ev[2 + 2d]: k_shade(d) done
