@@ -37,7 +37,9 @@
 #include "../../include/t3d.h"
 
 #define T3D_BLOCK 256
-#define T3D_TRACE_BLOCK 1024 /* k_trace: one atomic per queue counter per 1024 rays */
+#ifndef T3D_TRACE_BLOCK
+#define T3D_TRACE_BLOCK 256 /* k_trace: one atomic per queue counter per block of rays */
+#endif
 #define T3D_MAX_LIGHTS 64
 #define T3D_MAX_BOUNCES 14 /* heap index of the deepest node must fit 16 bits of the RNG key */
 
@@ -106,6 +108,7 @@ struct NodePool {
     float4* c;  // reflected slot rgb (child colour * attenuation), w = int bits: parent index
     float4* d;  // transmitted slot rgb, w = direct-light intensity
     int* dbg;   // debug record index of the node (only in single-pixel mode)
+    float* li;  // [levels * cap * L] direct-light intensity per (node, light), written by k_shade
 };
 
 struct Counters {
@@ -163,51 +166,83 @@ struct Hit {
     int back;  // sphere: 1 = hit from inside
 };
 
-__device__ __forceinline__ Hit closest_hit(const float4* __restrict__ tri_rows, int n_tris,
-                                           const DevSphere* __restrict__ spheres, int n_spheres, V3 o, V3 d,
-                                           bool lights, bool back_cull) {
-    float best = __builtin_inff();
-    int prim = -1;
-    int back = 0;
+// NR rays per lane share every triangle row: the rows arrive through the scalar data path once per
+// triangle and wave, so testing several rays against them divides that traffic (and the scalar-load
+// waits) by NR.
+// cull_limit[r]: 0 when back faces are rejected for ray r (only d.n < 0 counts), +inf when both sides
+// count.  The decision logic is arithmetic (min3 + one compare) instead of a chain of compares:
+//   m  = min(u, v, 1-u-v, |d.n| - 1e-6, cull_limit - d.n)      inside, not parallel, facing
+//   tt = m > 0 ? t : +inf
+//   closer  <=>  bits(tt) < bits(best) as UNSIGNED integers: true exactly for 0 <= tt < best, false for
+//   negative, +inf and NaN values (their bit patterns are above every non-negative finite float)
+template <int NR>
+__device__ __forceinline__ void closest_hit_n(const float4* __restrict__ tri_rows, int n_tris,
+                                              const DevSphere* __restrict__ spheres, int n_spheres, const V3 (&o)[NR],
+                                              const V3 (&d)[NR], bool lights, const bool (&back_cull)[NR], Hit (&out)[NR]) {
+    const uint32_t INF_BITS = 0x7f800000u;
+    uint32_t best[NR];
+    int prim[NR], back[NR];
+    float cull_limit[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { best[r] = INF_BITS; prim[r] = -1; back[r] = 0; cull_limit[r] = back_cull[r] ? 0.0f : __builtin_inff(); }
     // Triangles.  getFaceCollision (T3DR.py:624-651): reject |d.n| < 1e-6, t = (n.v0 - n.o) / (n.d),
     // reject t < 0, strict interior test, back faces rejected when back_cull.  First hit wins ties.
-#pragma unroll 2
     for (int i = 0; i < n_tris; ++i) {
         const float4 rn = tri_rows[3 * i + 0];
         const float4 ra = tri_rows[3 * i + 1];
         const float4 rb = tri_rows[3 * i + 2];
-        float dn = fmaf(rn.z, d.z, fmaf(rn.y, d.y, rn.x * d.x));
-        float q = fmaf(rn.z, o.z, fmaf(rn.y, o.y, fmaf(rn.x, o.x, -rn.w)));  // n.o - n.v0
-        float t = -q * __builtin_amdgcn_rcpf(dn);
-        float px = fmaf(d.x, t, o.x), py = fmaf(d.y, t, o.y), pz = fmaf(d.z, t, o.z);
-        float u = fmaf(ra.z, pz, fmaf(ra.y, py, fmaf(ra.x, px, ra.w)));
-        float v = fmaf(rb.z, pz, fmaf(rb.y, py, fmaf(rb.x, px, rb.w)));
-        bool ok = (u > 0.0f) & (v > 0.0f) & (u + v < 1.0f) & (t >= 0.0f) & (t < best) &
-                  (__builtin_fabsf(dn) >= 1e-6f) & ((dn < 0.0f) | !back_cull);
-        best = ok ? t : best;
-        prim = ok ? i : prim;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            float dn = fmaf(rn.z, d[r].z, fmaf(rn.y, d[r].y, rn.x * d[r].x));
+            float q = fmaf(rn.z, o[r].z, fmaf(rn.y, o[r].y, fmaf(rn.x, o[r].x, -rn.w)));  // n.o - n.v0
+            float t = -q * __builtin_amdgcn_rcpf(dn);
+            float px = fmaf(d[r].x, t, o[r].x), py = fmaf(d[r].y, t, o[r].y), pz = fmaf(d[r].z, t, o[r].z);
+            float u = fmaf(ra.z, pz, fmaf(ra.y, py, fmaf(ra.x, px, ra.w)));
+            float v = fmaf(rb.z, pz, fmaf(rb.y, py, fmaf(rb.x, px, rb.w)));
+            float w = (1.0f - u) - v;
+            float m = fminf(fminf(u, v), w);
+            m = fminf(fminf(m, __builtin_fabsf(dn) - 1e-6f), cull_limit[r] - dn);
+            uint32_t tt = (m > 0.0f) ? __float_as_uint(t) : INF_BITS;
+            bool closer = tt < best[r];
+            best[r] = closer ? tt : best[r];
+            prim[r] = closer ? i : prim[r];
+        }
     }
     // Spheres and lights.  getSphereCollision (T3DR.py:572-598), Ray.getTSphere (T3DE.py:145-163).
     for (int s = 0; s < n_spheres; ++s) {
         const DevSphere sp = spheres[s];
         if (sp.is_light && !lights) continue;  // wave-uniform
-        V3 L = mk(o.x - sp.cx, o.y - sp.cy, o.z - sp.cz);
-        float b = dot(L, d);
-        float c = dot(L, L) - sp.r2;
-        float disc = fmaf(b, b, -c);
-        float root = __builtin_sqrtf(fmaxf(disc, 0.0f));
-        float t1 = -b - root, t2 = -b + root;
-        bool front = t1 > 0.0f;
-        bool inside = (!front) & (t2 > 0.0f) & (!back_cull) & (sp.is_light == 0);
-        float t = front ? t1 : t2;
-        bool ok = (disc >= 0.0f) & (front | inside) & (t < best);
-        best = ok ? t : best;
-        prim = ok ? n_tris + s : prim;
-        back = ok ? (front ? 0 : 1) : back;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            V3 L = mk(o[r].x - sp.cx, o[r].y - sp.cy, o[r].z - sp.cz);
+            float b = dot(L, d[r]);
+            float c = dot(L, L) - sp.r2;
+            float disc = fmaf(b, b, -c);
+            float root = __builtin_sqrtf(fmaxf(disc, 0.0f));
+            float t1 = -b - root, t2 = -b + root;
+            bool front = t1 > 0.0f;
+            bool inside = (!front) & (t2 > 0.0f) & (!back_cull[r]) & (sp.is_light == 0);
+            float t = front ? t1 : t2;
+            bool ok = (disc >= 0.0f) & (front | inside);
+            uint32_t tt = ok ? __float_as_uint(t) : INF_BITS;
+            bool closer = tt < best[r];
+            best[r] = closer ? tt : best[r];
+            prim[r] = closer ? n_tris + s : prim[r];
+            back[r] = closer ? (front ? 0 : 1) : back[r];
+        }
     }
-    Hit h;
-    h.t = best; h.prim = prim; h.back = back;
-    return h;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { out[r].t = __uint_as_float(best[r]); out[r].prim = prim[r]; out[r].back = back[r]; }
+}
+
+__device__ __forceinline__ Hit closest_hit(const float4* __restrict__ tri_rows, int n_tris,
+                                           const DevSphere* __restrict__ spheres, int n_spheres, V3 o, V3 d,
+                                           bool lights, bool back_cull) {
+    const V3 oo[1] = {o}, dd[1] = {d};
+    const bool bc[1] = {back_cull};
+    Hit h[1];
+    closest_hit_n<1>(tri_rows, n_tris, spheres, n_spheres, oo, dd, lights, bc, h);
+    return h[0];
 }
 
 // wave64 compaction: index in [*counter .. ) for every lane with pred, one atomic per wave
@@ -422,10 +457,13 @@ __global__ __launch_bounds__(T3D_TRACE_BLOCK) void k_trace(DevScene sc, const fl
         const unsigned long long m_n = __ballot(shaded), m_t = __ballot(want_t), m_b = __ballot(want_b);
         if (lane == 0) { s_cnt[wid][0] = __popcll(m_n); s_cnt[wid][1] = __popcll(m_t); s_cnt[wid][2] = __popcll(m_b); }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            int tn = 0, tr = 0;
-            for (int w = 0; w < T3D_TRACE_BLOCK / 64; ++w) { tn += s_cnt[w][0]; tr += s_cnt[w][1] + s_cnt[w][2]; }
+        if (threadIdx.x == 0) {           // wave 0 reserves node slots, wave 1 child-ray slots: the two atomics overlap
+            int tn = 0;
+            for (int w = 0; w < T3D_TRACE_BLOCK / 64; ++w) tn += s_cnt[w][0];
             s_base[0] = tn ? atomicAdd(&cnt->n_nodes[level], tn) : 0;
+        } else if (threadIdx.x == 64) {
+            int tr = 0;
+            for (int w = 0; w < T3D_TRACE_BLOCK / 64; ++w) tr += s_cnt[w][1] + s_cnt[w][2];
             s_base[1] = tr ? atomicAdd(&cnt->n_rays[level + 1], tr) : 0;
         }
         __syncthreads();
@@ -473,50 +511,69 @@ __global__ __launch_bounds__(T3D_TRACE_BLOCK) void k_trace(DevScene sc, const fl
 // ------------------------------------------------------------------------------------------------
 // k_shade: getDirectLight (T3DR.py:820-900) + getVisibility (T3DR.py:762-778) for one level's nodes
 // ------------------------------------------------------------------------------------------------
+#ifndef T3D_SHADE_NR
+#define T3D_SHADE_NR 2
+#endif
+// Work item p = (node p / L, light p % L); every lane takes T3D_SHADE_NR consecutive items and traces
+// their shadow rays together.  The intensity of item p goes to light_i[p]; k_resolve adds the L values
+// of a node in light order, as getDirectLight does.
 __global__ __launch_bounds__(T3D_BLOCK) void k_shade(DevScene sc, const float4* __restrict__ tri_rows,
                                                      const DevSphere* __restrict__ spheres, RenderParams rp, int level,
                                                      NodePool pool, const Counters* __restrict__ cnt) {
-    const int n = min(cnt->n_nodes[level], rp.cap);
-    const int stride = gridDim.x * blockDim.x;
-    const int iters = (n + stride - 1) / stride;
+    constexpr int NR = T3D_SHADE_NR;
+    const int L = sc.n_lights;
+    const long long n_items = (long long)min(cnt->n_nodes[level], rp.cap) * L;
+    const long long stride = (long long)gridDim.x * blockDim.x * NR;
     const size_t node_base = (size_t)level * rp.cap;
     const V3 cam = mk(sc.cam.pos[0], sc.cam.pos[1], sc.cam.pos[2]);
-    for (int it = 0; it < iters; ++it) {
-        const int i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
-        const bool active = i < n;
-        if (!__any(active)) break;  // whole wave past the end of the node list (wave-uniform)
-        const size_t g = node_base + (size_t)(active ? i : 0);
-        float4 a = pool.a[g], b = pool.b[g];
-        V3 P = mk(a.x, a.y, a.z), N = mk(b.x, b.y, b.z);
-        int shader = __float_as_int(b.w) & 0x3FFFFFFF;
-        float rough = sc.shaders[shader].rough;
-        V3 view = normalize(cam - P);
-        float total = 0.0f;
-        for (int l = 0; l < sc.n_lights; ++l) {
-            DevLight lt = sc.lights[l];
-            V3 to = mk(lt.x - P.x, lt.y - P.y, lt.z - P.z);
-            float dist2 = dot(to, to);
-            V3 Ld = to * __builtin_amdgcn_rsqf(dist2);
-            V3 start = madd(P, Ld, 0.2f);
-            Hit h = closest_hit(tri_rows, sc.n_tris, spheres, sc.n_spheres, start, Ld, true, false);
+    for (long long first = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * NR; ; first += stride) {
+        if (!__any(first < n_items)) break;  // whole wave past the end (wave-uniform)
+        V3 o[NR], d[NR], N[NR], view[NR];
+        bool cull[NR];
+        float dist2[NR], rough[NR], strength[NR];
+        bool active[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const long long p = first + r;
+            active[r] = p < n_items;
+            const long long pp = active[r] ? p : 0;
+            const int j = (int)(pp / L), l = (int)(pp - (long long)j * L);
+            const size_t g = node_base + (size_t)j;
+            const float4 a = pool.a[g], b = pool.b[g];
+            const V3 P = mk(a.x, a.y, a.z);
+            N[r] = mk(b.x, b.y, b.z);
+            rough[r] = sc.shaders[__float_as_int(b.w) & 0x3FFFFFFF].rough;
+            view[r] = normalize(cam - P);
+            const DevLight lt = sc.lights[l];
+            const V3 to = mk(lt.x - P.x, lt.y - P.y, lt.z - P.z);
+            dist2[r] = dot(to, to);
+            d[r] = to * __builtin_amdgcn_rsqf(dist2[r]);
+            o[r] = madd(P, d[r], 0.2f);
+            strength[r] = lt.strength;
+            cull[r] = false;
+        }
+        Hit h[NR];
+        closest_hit_n<NR>(tri_rows, sc.n_tris, spheres, sc.n_spheres, o, d, true, cull, h);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
             float vis = 1.0f;
-            if (h.prim >= 0) {
-                if (h.prim < sc.n_tris) {
-                    DevShader bs = sc.shaders[sc.tri_meta[h.prim].z];
+            if (h[r].prim >= 0) {
+                if (h[r].prim < sc.n_tris) {
+                    DevShader bs = sc.shaders[sc.tri_meta[h[r].prim].z];
                     if (!(bs.emis > 0.0f)) vis = 1.0f - bs.refl;
                 } else {
-                    DevSphere sp = spheres[h.prim - sc.n_tris];
+                    DevSphere sp = spheres[h[r].prim - sc.n_tris];
                     if (!sp.is_light) vis = 1.0f - sc.shaders[sp.shader].refl;
                 }
             }
-            float ldn = dot(Ld, N);
+            float ldn = dot(d[r], N[r]);
             float diffuse = fmaxf(0.0f, ldn);
-            V3 R = madd(Ld * -1.0f, N, 2.0f * ldn);
-            float spec = (dot(normalize(R), view) < 0.96f) ? 0.0f : 1.0f;
-            float att = attenuation(dist2);
-            total += (diffuse * rough + spec * (1.0f - rough)) * lt.strength * vis * att;
+            V3 R = madd(d[r] * -1.0f, N[r], 2.0f * ldn);
+            float spec = (dot(normalize(R), view[r]) < 0.96f) ? 0.0f : 1.0f;
+            float att = attenuation(dist2[r]);
+            float I = (diffuse * rough[r] + spec * (1.0f - rough[r])) * strength[r] * vis * att;
+            if (active[r]) pool.li[node_base * L + (size_t)(first + r)] = I;
         }
-        if (active) pool.d[g].w = total;
     }
 }
 
@@ -535,7 +592,8 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_resolve(DevScene sc, RenderParams
         int shader = meta & 0x3FFFFFFF, side = (meta >> 30) & 1;
         int parent = __float_as_int(c.w);
         DevShader sh = sc.shaders[shader];
-        float refl = sh.refl, tf = 1.0f - refl, I = d.w;
+        float refl = sh.refl, tf = 1.0f - refl, I = 0.0f;
+        for (int l = 0; l < sc.n_lights; ++l) I += pool.li[g * sc.n_lights + l];  // light order, T3DR.py:894
         float col[3] = {sh.r, sh.g, sh.b};
         float rs[3] = {c.x, c.y, c.z}, ts[3] = {d.x, d.y, d.z};
         float res[3];
@@ -631,7 +689,7 @@ struct t3d_ctx {
     void* d_shaders = nullptr; void* d_obj_ior = nullptr;
     int n_objects = 0, n_sphere_objs = 0, n_light_objs = 0;
     // work buffers
-    size_t cap_alloc = 0; int levels_alloc = 0;
+    size_t cap_alloc = 0; int levels_alloc = 0; int li_lights = 0;
     RayRec* d_rays[2] = {nullptr, nullptr};
     NodePool pool{};
     size_t n0_alloc = 0;
@@ -703,7 +761,7 @@ static void free_scene(t3d_ctx* c) {
 }
 static void free_work(t3d_ctx* c) {
     hipFree(c->d_rays[0]); hipFree(c->d_rays[1]); hipFree(c->pool.a); hipFree(c->pool.b); hipFree(c->pool.c);
-    hipFree(c->pool.d); hipFree(c->pool.dbg);
+    hipFree(c->pool.d); hipFree(c->pool.dbg); hipFree(c->pool.li);
     c->d_rays[0] = c->d_rays[1] = nullptr; c->pool = NodePool{}; c->cap_alloc = 0; c->levels_alloc = 0;
 }
 
@@ -809,7 +867,7 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
 }
 
 static int ensure_work(t3d_ctx* c, size_t cap, int levels, size_t n0, bool dbg) {
-    if (cap > c->cap_alloc || levels > c->levels_alloc || (dbg && !c->pool.dbg)) {
+    if (cap > c->cap_alloc || levels > c->levels_alloc || (dbg && !c->pool.dbg) || c->sc.n_lights > c->li_lights) {
         free_work(c);
         size_t cap2 = cap, lv = (size_t)levels;
         HIPCHK(c, hipMalloc((void**)&c->d_rays[0], sizeof(RayRec) * cap2));
@@ -819,6 +877,8 @@ static int ensure_work(t3d_ctx* c, size_t cap, int levels, size_t n0, bool dbg) 
         HIPCHK(c, hipMalloc((void**)&c->pool.c, sizeof(float4) * cap2 * lv));
         HIPCHK(c, hipMalloc((void**)&c->pool.d, sizeof(float4) * cap2 * lv));
         if (dbg) HIPCHK(c, hipMalloc((void**)&c->pool.dbg, sizeof(int) * cap2 * lv));
+        HIPCHK(c, hipMalloc((void**)&c->pool.li, sizeof(float) * cap2 * lv * (size_t)(c->sc.n_lights > 0 ? c->sc.n_lights : 1)));
+        c->li_lights = c->sc.n_lights;
         c->cap_alloc = cap2; c->levels_alloc = levels;
     }
     if (n0 > c->n0_alloc) {
@@ -901,7 +961,7 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
     TraceOut out{c->d_sample_color, d_prim, d_prim_t, d_dbg, dbg_cap};
     const int max_blocks = c->n_sm * 8;
     auto blocks_for = [&](size_t n) { size_t b = (n + T3D_BLOCK - 1) / T3D_BLOCK; return (int)(b < 1 ? 1 : (b > (size_t)max_blocks ? (size_t)max_blocks : b)); };
-    auto trace_blocks_for = [&](size_t n) { size_t b = (n + T3D_TRACE_BLOCK - 1) / T3D_TRACE_BLOCK; size_t mx = (size_t)c->n_sm * 2; return (int)(b < 1 ? 1 : (b > mx ? mx : b)); };
+    auto trace_blocks_for = [&](size_t n) { size_t b = (n + T3D_TRACE_BLOCK - 1) / T3D_TRACE_BLOCK; size_t mx = (size_t)c->n_sm * (2048 / T3D_TRACE_BLOCK); return (int)(b < 1 ? 1 : (b > mx ? mx : b)); };
     uint64_t launches = 0;
     // per-launch timing: event 2d+1 after k_trace(d), 2d+2 after k_shade(d); read by fill_stats
     int n_timed = 0;
@@ -917,7 +977,7 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
         else
             hipLaunchKernelGGL(k_trace<false>, dim3(single ? 1 : trace_blocks_for(c->cap_alloc)), dim3(T3D_TRACE_BLOCK), 0, st, c->sc, rows, sph, rp, d, in, outq, c->pool, c->d_cnt, out);
         HIPCHK(c, tick());  // ev[1 + 2d]: k_trace(d) done
-        hipLaunchKernelGGL(k_shade, dim3(single ? 1 : (d == 0 ? blocks_for(n0) : max_blocks)), dim3(T3D_BLOCK), 0, st, c->sc, rows, sph, rp, d, c->pool, c->d_cnt);
+        hipLaunchKernelGGL(k_shade, dim3(single ? 1 : max_blocks), dim3(T3D_BLOCK), 0, st, c->sc, rows, sph, rp, d, c->pool, c->d_cnt);
         HIPCHK(c, tick());  // ev[2 + 2d]: k_shade(d) done
         launches += 2;
     }

@@ -1,0 +1,21 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root): tools/gpu_bench_profile.sh <tag>
+# runs the GPU tests, then bench.py under rocprofv3 --kernel-trace --stats, prints a summary
+set -o pipefail
+tag=$1
+R=$GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+timeout -k 10 400 python -u -m pytest tests -m gpu -x -q --timeout 180 --timeout-method thread > gpurun_out/tests_$tag.log 2>&1
+rc=$?
+tail -3 gpurun_out/tests_$tag.log
+if [ $rc -ne 0 ]; then echo "TESTS FAILED rc=$rc"; grep -E "^(FAILED|E  )" gpurun_out/tests_$tag.log | head -20; exit $rc; fi
+cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_${tag}_bench.json 2> $R/gpurun_out/prof_$tag.err
+rc=$?
+cd $R
+if [ $rc -ne 0 ]; then echo "BENCH FAILED rc=$rc"; tail -20 gpurun_out/prof_$tag.err; exit $rc; fi
+python tools/prof_summary.py gpurun_out/prof_$tag/*/*_kernel_trace.csv
+python - <<PY
+import json
+d=json.load(open("gpurun_out/prof_${tag}_bench.json"))
+print("value", d["value"], "Mrays/s  ms/frame", d["ms_per_step"], " k_shade frac", d["roofline"]["frac"], " k_trace TF", d["roofline"]["k_trace"]["achieved"])
+PY
