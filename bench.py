@@ -11,9 +11,10 @@ One step = one complete frame: every rank traces its interleaved image rows thro
 one closest-hit query (primary + bounce + transmit + shadow).  Prints ONE JSON line on rank 0.
 
 The line also carries
-  roofline      FP32 vector-ALU roofline of the dominant kernel (k_shade, the shadow-ray closest-hit
-                kernel): algorithmic flops (51 per ray-triangle test, 19 per ray-sphere test) divided by
-                the kernel's launch durations, measured with HIP events in the last timed step
+  roofline      FP32 vector-ALU roofline of the dominant kernel (k_level, which runs every closest-hit
+                query of a tree level): algorithmic flops (51 per ray-triangle test, 19 per ray-sphere
+                test) divided by the kernel's launch durations, measured with HIP events in the last
+                timed step
   cpu_baseline  the float64 CPU oracle (oracle/, a restatement of the reference's algorithm) timed on this
                 host's cores on a bounded sample of the same frame (N = 1 only)
 """
@@ -134,13 +135,12 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = totals["queries"] * args.steps / elapsed / 1e6
-        # roofline of the dominant kernel on this rank (k_shade): algorithmic flops / measured kernel time
+        # roofline of the dominant kernel on this rank (k_level: every closest-hit query of the frame):
+        # algorithmic flops / measured kernel time
         T, S = flat.n_tris, flat.n_spheres
-        flops_shade = last["shadow_queries"] * (FLOP_PER_TRI_TEST * T + FLOP_PER_SPHERE_TEST * S)
-        flops_trace = last["trace_queries"] * (FLOP_PER_TRI_TEST * T + FLOP_PER_SPHERE_TEST * S)
-        shade_s = last["ms_k_shade"] * 1e-3
-        trace_s = last["ms_k_trace"] * 1e-3
-        achieved = flops_shade / shade_s / 1e12 if shade_s > 0 else 0.0
+        flops = last["queries"] * (FLOP_PER_TRI_TEST * T + FLOP_PER_SPHERE_TEST * S)
+        level_s = last["ms_k_level"] * 1e-3
+        achieved = flops / level_s / 1e12 if level_s > 0 else 0.0
         line = {
             "metric": "Mrays/s (primary+secondary closest-hit queries), Cornell 1080p 4 bounces",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -150,12 +150,12 @@ def main():
                        "samples": options["samples"], "triangles": T, "spheres_and_lights": S,
                        "lights": int(len(flat.light_strength)), "partition": f"{args.partition} rows x{world}",
                        "queries_per_frame": totals["queries"], "rendered_rays_per_frame": totals["rays_api"]},
-            "roofline": {"bound": "valu", "kernel": "k_shade", "achieved": round(achieved, 3), "peak": FP32_VALU_PEAK_TFLOPS,
+            "roofline": {"bound": "valu", "kernel": "k_level", "achieved": round(achieved, 3), "peak": FP32_VALU_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4), "traffic": None,
-                         "launches_per_frame": last["n_k_shade"], "avg_launch_ms": round(last["ms_k_shade"] / max(1, last["n_k_shade"]), 5),
-                         "flops_per_frame": flops_shade,
-                         "k_trace": {"achieved": round(flops_trace / trace_s / 1e12, 3) if trace_s > 0 else 0.0,
-                                     "avg_launch_ms": round(last["ms_k_trace"] / max(1, last["n_k_trace"]), 5)},
+                         "launches_per_frame": last["n_k_level"],
+                         "avg_launch_ms": round(last["ms_k_level"] / max(1, last["n_k_level"]), 5),
+                         "flops_per_launch": flops / max(1, last["n_k_level"]),
+                         "queries_per_launch": last["queries"] / max(1, last["n_k_level"]),
                          "frame_device_ms": round(last["ms_device"], 4), "resolve_ms": round(last["ms_resolve"], 4)},
         }
         if world == 1 and not args.no_cpu_baseline:

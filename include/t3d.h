@@ -89,23 +89,21 @@ typedef struct t3d_opts {
     double ambient[3];  /* options['ambient'] r,g,b                                                */
 } t3d_opts;
 
-#define T3D_STATS_N_COUNTERS 11
+#define T3D_STATS_N_COUNTERS 10
 typedef struct t3d_stats {
     /* T3D_STATS_N_COUNTERS integer counters first, then the timings */
     uint64_t rays_api;       /* Rendered.rays: primary samples + shadow rays (T3DR.py:842, 1211)     */
     uint64_t queries;        /* closest-hit queries: primary + bounce + transmit + shadow            */
-    uint64_t trace_queries;  /* of which traced by k_trace (primary, bounce, transmit)                */
-    uint64_t shadow_queries; /* of which traced by k_shade (one per light per shaded node)           */
+    uint64_t trace_queries;  /* of which tree rays (primary, bounce, transmit)                        */
+    uint64_t shadow_queries; /* of which shadow rays (one per light per shaded node)                  */
     uint64_t tri_tests;      /* ray-triangle tests executed                                          */
     uint64_t sphere_tests;   /* ray-sphere tests executed                                            */
     uint64_t aabb_tests;     /* ray-box tests executed                                               */
     uint64_t nodes;          /* shaded trace-tree nodes (emitter leaves are folded into the parent)  */
     uint64_t launches;       /* kernel launches issued                                               */
-    uint64_t n_k_trace;      /* launches of k_trace                                                  */
-    uint64_t n_k_shade;      /* launches of k_shade                                                  */
+    uint64_t n_k_level;      /* launches of k_level, the closest-hit kernel (one per tree level)     */
     double ms_device;        /* device time of the whole call (HIP events on the launch stream)      */
-    double ms_k_trace;       /* sum of k_trace launch durations                                      */
-    double ms_k_shade;       /* sum of k_shade launch durations                                      */
+    double ms_k_level;       /* sum of the k_level launch durations                                  */
     double ms_resolve;       /* colour resolve + image store                                         */
 } t3d_stats;
 

@@ -34,9 +34,8 @@ assert NODE_DTYPE.itemsize == C.sizeof(ONode)
 
 def build(force=False):
     """Compile the oracle with its Makefile (gcc, a second or two)."""
-    if force or not os.path.exists(LIB_PATH) or \
-            os.path.getmtime(LIB_PATH) < os.path.getmtime(os.path.join(HERE, "t3d_oracle.c")):
-        subprocess.check_call(["make", "-s", "-C", HERE])
+    # make decides: the library depends on the C file and on both headers (struct layouts)
+    subprocess.check_call(["make", "-s", "-C", HERE] + (["-B"] if force else []))
     return LIB_PATH
 
 

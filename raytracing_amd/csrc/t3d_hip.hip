@@ -4,12 +4,13 @@
 // level by level of the trace tree (T3DR.py:959-1001):
 //
 //   for depth d = 0 .. bounces:
-//       k_trace   one thread per ray of level d: closest hit over all primitives, classify the
-//                 hit (miss / emitter leaf / shaded node), append the shaded node to the level's
-//                 node array and the reflected / transmitted child rays to the next level's ray
-//                 queue (wave64 ballot + prefix popcount, one atomic per wave)
-//       k_shade   one thread per shaded node of level d: one closest-hit shadow query per light,
-//                 accumulates the direct-light intensity (T3DR.py:820-900)
+//       k_level   per 256-thread block a scheduler over two kinds of closest-hit rounds:
+//                 trace round: one ray of level d per lane -- closest hit over all primitives, classify
+//                 (miss / emitter leaf / shaded node), append the node to the level's node array and the
+//                 reflected / transmitted child rays to the next level's queue (wave64 ballot + prefix
+//                 popcount, one atomic per counter per block);
+//                 shadow round: one (node, light) pair per lane from an LDS ring of the block's shaded
+//                 nodes -- shadow-ray closest hit, direct-light intensity (T3DR.py:820-900)
 //   for depth d = bounces .. 0:
 //       k_resolve one thread per node: computeColor (T3DR.py:1004-1083) from the two child slots
 //                 and the direct light, pushes the colour into the parent's slot
@@ -38,7 +39,7 @@
 
 #define T3D_BLOCK 256
 #ifndef T3D_TRACE_BLOCK
-#define T3D_TRACE_BLOCK 256 /* k_trace: one atomic per queue counter per block of rays */
+#define T3D_TRACE_BLOCK 256 /* k_level block: one atomic per queue counter per 256 rays */
 #endif
 #define T3D_MAX_LIGHTS 64
 #define T3D_MAX_BOUNCES 14 /* heap index of the deepest node must fit 16 bits of the RNG key */
@@ -108,12 +109,17 @@ struct NodePool {
     float4* c;  // reflected slot rgb (child colour * attenuation), w = int bits: parent index
     float4* d;  // transmitted slot rgb, w = direct-light intensity
     int* dbg;   // debug record index of the node (only in single-pixel mode)
-    float* li;  // [levels * cap * L] direct-light intensity per (node, light), written by k_shade
+    float* li;  // [levels * cap * L] direct-light intensity per (node, light), written by k_level
 };
 
+#define T3D_SHARDS 64 /* queue shards per level; the launch's wave count is a multiple of it */
+struct alignas(64) PaddedCount {
+    int v;
+    int pad[15];
+};
 struct Counters {
-    int n_rays[T3D_MAX_BOUNCES + 2];
-    int n_nodes[T3D_MAX_BOUNCES + 2];
+    PaddedCount n_rays[T3D_MAX_BOUNCES + 2][T3D_SHARDS];   // rays queued for each level, per shard
+    PaddedCount n_nodes[T3D_MAX_BOUNCES + 2][T3D_SHARDS];  // shaded nodes of each level, per shard
     int overflow;
     int n_dbg;
 };
@@ -235,6 +241,77 @@ __device__ __forceinline__ void closest_hit_n(const float4* __restrict__ tri_row
     for (int r = 0; r < NR; ++r) { out[r].t = __uint_as_float(best[r]); out[r].prim = prim[r]; out[r].back = back[r]; }
 }
 
+// Two rays per lane in PACKED float32: on gfx950 a wave64 v_fma_f32 occupies its SIMD for 4 cycles, and so
+// does a v_pk_fma_f32 that does two FMAs per lane -- the FP32 vector peak (157 TFLOP/s) is a packed-math
+// peak.  The two rays of a lane sit in the two halves of 64-bit register pairs; dot products, the hit
+// point and the barycentrics are v_pk_fma/v_pk_mul/v_pk_add, only rcp and the min3/compare/select
+// decision run once per ray.  Same decision logic as closest_hit_n; |d.n| >= 1e-6 is tested as
+// (d.n)^2 - 1e-12 > 0 because packed instructions have no |x| operand modifier.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 splat(float s) { return (f2)(s); }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+__device__ __forceinline__ void closest_hit2(const float4* __restrict__ tri_rows, int n_tris,
+                                             const DevSphere* __restrict__ spheres, int n_spheres, const V3 (&o)[2],
+                                             const V3 (&d)[2], bool lights, const bool (&back_cull)[2], Hit (&out)[2]) {
+    const uint32_t INF_BITS = 0x7f800000u;
+    const f2 ox = {o[0].x, o[1].x}, oy = {o[0].y, o[1].y}, oz = {o[0].z, o[1].z};
+    const f2 dx = {d[0].x, d[1].x}, dy = {d[0].y, d[1].y}, dz = {d[0].z, d[1].z};
+    const f2 cull = {back_cull[0] ? 0.0f : __builtin_inff(), back_cull[1] ? 0.0f : __builtin_inff()};
+    uint32_t best0 = INF_BITS, best1 = INF_BITS;
+    int prim0 = -1, prim1 = -1, back0 = 0, back1 = 0;
+    for (int i = 0; i < n_tris; ++i) {
+        const float4 rn = tri_rows[3 * i + 0];
+        const float4 ra = tri_rows[3 * i + 1];
+        const float4 rb = tri_rows[3 * i + 2];
+        const f2 dn = fma2(splat(rn.z), dz, fma2(splat(rn.y), dy, splat(rn.x) * dx));
+        const f2 q = fma2(splat(rn.z), oz, fma2(splat(rn.y), oy, fma2(splat(rn.x), ox, splat(-rn.w))));  // n.o - n.v0
+        const f2 inv = {__builtin_amdgcn_rcpf(dn.x), __builtin_amdgcn_rcpf(dn.y)};
+        const f2 t = -q * inv;
+        const f2 px = fma2(dx, t, ox), py = fma2(dy, t, oy), pz = fma2(dz, t, oz);
+        const f2 u = fma2(splat(ra.z), pz, fma2(splat(ra.y), py, fma2(splat(ra.x), px, splat(ra.w))));
+        const f2 v = fma2(splat(rb.z), pz, fma2(splat(rb.y), py, fma2(splat(rb.x), px, splat(rb.w))));
+        const f2 w = (splat(1.0f) - u) - v;
+        const f2 e = fma2(dn, dn, splat(-1e-12f));
+        const f2 c = cull - dn;
+        const float m0 = fminf(fminf(fminf(u.x, v.x), w.x), fminf(e.x, c.x));
+        const float m1 = fminf(fminf(fminf(u.y, v.y), w.y), fminf(e.y, c.y));
+        const uint32_t tt0 = (m0 > 0.0f) ? __float_as_uint(t.x) : INF_BITS;
+        const uint32_t tt1 = (m1 > 0.0f) ? __float_as_uint(t.y) : INF_BITS;
+        const bool cl0 = tt0 < best0, cl1 = tt1 < best1;
+        best0 = cl0 ? tt0 : best0; prim0 = cl0 ? i : prim0;
+        best1 = cl1 ? tt1 : best1; prim1 = cl1 ? i : prim1;
+    }
+    for (int s = 0; s < n_spheres; ++s) {
+        const DevSphere sp = spheres[s];
+        if (sp.is_light && !lights) continue;  // wave-uniform
+        const f2 Lx = ox - splat(sp.cx), Ly = oy - splat(sp.cy), Lz = oz - splat(sp.cz);
+        const f2 b = fma2(Lz, dz, fma2(Ly, dy, Lx * dx));
+        const f2 cc = fma2(Lz, Lz, fma2(Ly, Ly, Lx * Lx)) - splat(sp.r2);
+        const f2 disc = fma2(b, b, -cc);
+        const f2 root = {__builtin_sqrtf(fmaxf(disc.x, 0.0f)), __builtin_sqrtf(fmaxf(disc.y, 0.0f))};
+        const f2 t1 = -b - root, t2 = -b + root;
+        {
+            const bool front = t1.x > 0.0f;
+            const bool inside = (!front) & (t2.x > 0.0f) & (!back_cull[0]) & (sp.is_light == 0);
+            const bool ok = (disc.x >= 0.0f) & (front | inside);
+            const uint32_t tt = ok ? __float_as_uint(front ? t1.x : t2.x) : INF_BITS;
+            const bool closer = tt < best0;
+            best0 = closer ? tt : best0; prim0 = closer ? n_tris + s : prim0; back0 = closer ? (front ? 0 : 1) : back0;
+        }
+        {
+            const bool front = t1.y > 0.0f;
+            const bool inside = (!front) & (t2.y > 0.0f) & (!back_cull[1]) & (sp.is_light == 0);
+            const bool ok = (disc.y >= 0.0f) & (front | inside);
+            const uint32_t tt = ok ? __float_as_uint(front ? t1.y : t2.y) : INF_BITS;
+            const bool closer = tt < best1;
+            best1 = closer ? tt : best1; prim1 = closer ? n_tris + s : prim1; back1 = closer ? (front ? 0 : 1) : back1;
+        }
+    }
+    out[0].t = __uint_as_float(best0); out[0].prim = prim0; out[0].back = back0;
+    out[1].t = __uint_as_float(best1); out[1].prim = prim1; out[1].back = back1;
+}
+
 __device__ __forceinline__ Hit closest_hit(const float4* __restrict__ tri_rows, int n_tris,
                                            const DevSphere* __restrict__ spheres, int n_spheres, V3 o, V3 d,
                                            bool lights, bool back_cull) {
@@ -258,7 +335,7 @@ __device__ __forceinline__ int wave_append(int* counter, bool pred) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_trace
+// k_level helpers
 // ------------------------------------------------------------------------------------------------
 struct TraceOut {
     float4* sample_color;  // [N0] rgb of a finished sample (w unused)
@@ -282,297 +359,320 @@ __device__ __forceinline__ void camera_ray(const DevCamera& cam, const RenderPar
     d = normalize(v);
 }
 
+// Direct-light terms of two (node, light) pairs per lane: getDirectLight for one light each
+// (T3DR.py:839-894) with getVisibility (T3DR.py:762-778).  The shadow rays see both faces and Light objects.
+__device__ __forceinline__ void shadow_items2(const DevScene& sc, const float4* __restrict__ tri_rows,
+                                              const DevSphere* __restrict__ spheres, const V3 (&P)[2], const V3 (&N)[2],
+                                              const float (&rough)[2], const int (&l)[2], float (&I)[2]) {
+    const V3 cam = mk(sc.cam.pos[0], sc.cam.pos[1], sc.cam.pos[2]);
+    V3 Ld[2], start[2];
+    float dist2[2], strength[2];
+    const bool cull[2] = {false, false};
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const DevLight lt = sc.lights[l[r]];
+        const V3 to = mk(lt.x - P[r].x, lt.y - P[r].y, lt.z - P[r].z);
+        dist2[r] = dot(to, to);
+        Ld[r] = to * __builtin_amdgcn_rsqf(dist2[r]);
+        start[r] = madd(P[r], Ld[r], 0.2f);
+        strength[r] = lt.strength;
+    }
+    Hit h[2];
+    closest_hit2(tri_rows, sc.n_tris, spheres, sc.n_spheres, start, Ld, true, cull, h);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        float vis = 1.0f;
+        if (h[r].prim >= 0) {
+            if (h[r].prim < sc.n_tris) {
+                DevShader bs = sc.shaders[sc.tri_meta[h[r].prim].z];
+                if (!(bs.emis > 0.0f)) vis = 1.0f - bs.refl;
+            } else {
+                DevSphere sp = spheres[h[r].prim - sc.n_tris];
+                if (!sp.is_light) vis = 1.0f - sc.shaders[sp.shader].refl;
+            }
+        }
+        const float ldn = dot(Ld[r], N[r]);
+        const float diffuse = fmaxf(0.0f, ldn);
+        const V3 R = madd(Ld[r] * -1.0f, N[r], 2.0f * ldn);
+        const float spec = (dot(normalize(R), normalize(cam - P[r])) < 0.96f) ? 0.0f : 1.0f;
+        I[r] = (diffuse * rough[r] + spec * (1.0f - rough[r])) * strength[r] * vis * attenuation(dist2[r]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_level: everything one tree level needs, one launch.
+//
+// Every WAVE is an autonomous scheduler over two kinds of closest-hit work, one query per lane per round:
+//   trace round   the next 64 rays of the level's queue: closest hit, classification, child rays,
+//                 node records; the shaded nodes also enter the wave's ring buffer in LDS
+//   shadow round  64 (node, light) pairs from the ring: shadow-ray closest hit -> li[node][light]
+// A shadow round runs whenever 64 pairs are pending (or the queue is exhausted), so lanes stay busy even
+// though only part of the rays produce shaded nodes, and node data for shading never leaves LDS.
+// There is no block-level synchronisation at all.
+//
+// Queues are sharded T3D_SHARDS ways: wave w appends to shard w % T3D_SHARDS (own counter in its own
+// 64-byte line, own slice of the arrays) with wave64 ballot + prefix-popcount compaction and ONE atomic
+// per counter per round.  Same-address device-scope atomics retire at roughly one per 7 ns, so a single
+// counter per level would serialise the whole kernel; 64 counters do not.
+// ------------------------------------------------------------------------------------------------
+#define T3D_RING 192 /* nodes per wave; pending pairs < 128 before a trace round, which adds at most 64 nodes */
 template <bool LEVEL0>
-__global__ __launch_bounds__(T3D_TRACE_BLOCK) void k_trace(DevScene sc, const float4* __restrict__ tri_rows,
+__global__ __launch_bounds__(T3D_TRACE_BLOCK) void k_level(DevScene sc, const float4* __restrict__ tri_rows,
                                                      const DevSphere* __restrict__ spheres, RenderParams rp, int level,
                                                      const RayRec* __restrict__ rays_in, RayRec* __restrict__ rays_out,
                                                      NodePool pool, Counters* cnt, TraceOut out) {
-    const int n = LEVEL0 ? rp.n0 : min(cnt->n_rays[level], rp.cap);
-    const size_t node_base = (size_t)level * rp.cap;
-    // queue appends are aggregated per block: every wave ballots, wave 0 adds the block totals to the
-    // global counters with ONE atomic per counter, then each lane derives its slot from prefix counts
-    __shared__ int s_cnt[T3D_TRACE_BLOCK / 64][3];
-    __shared__ int s_base[2];
+    __shared__ float4 ring_a[T3D_TRACE_BLOCK / 64][T3D_RING];  // P.xyz, roughness
+    __shared__ float4 ring_b[T3D_TRACE_BLOCK / 64][T3D_RING];  // unit normal, int bits: node index within the level
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    for (int chunk = blockIdx.x; (long long)chunk * T3D_TRACE_BLOCK < n; chunk += gridDim.x) {
-        const int i = chunk * T3D_TRACE_BLOCK + threadIdx.x;
-        const bool active = i < n;
-        V3 o = mk(0, 0, 0), d = mk(0, 0, 1), pstart = mk(0, 0, 0);
-        float ior = 1.0f;
-        int inside_obj = -1, parent = -1, side = 0, dbg_parent = -1;
-        uint32_t ps = 0, heap = 1;
-        int px = 0, py = 0, smp = 0;
-        if (active) {
-            if (LEVEL0) {
-                ps = (uint32_t)i;
-                int pix = i / rp.samples;
-                smp = i - pix * rp.samples;
-                int ly = pix / rp.width;
-                px = pix - ly * rp.width;
-                py = rp.row0 + ly * rp.row_stride;
-                if (rp.single) { px = rp.px0; py = rp.py0; smp = rp.sample0; }
-                camera_ray(sc.cam, rp, px, py, o, d);
-                parent = i;
-            } else {
-                RayRec r = rays_in[i];
-                o = mk(r.o.x, r.o.y, r.o.z); ior = r.o.w;
-                d = mk(r.d.x, r.d.y, r.d.z); inside_obj = __float_as_int(r.d.w);
-                pstart = mk(r.p.x, r.p.y, r.p.z); parent = __float_as_int(r.p.w);
-                ps = r.k.x; heap = r.k.y; side = (int)r.k.z; dbg_parent = (int)r.k.w;
+    const int gw = blockIdx.x * (T3D_TRACE_BLOCK / 64) + wid;      // global wave id
+    const int nw = gridDim.x * (T3D_TRACE_BLOCK / 64);             // multiple of T3D_SHARDS (host guarantees)
+    const int shard = gw % T3D_SHARDS;
+    const int shard_cap = rp.cap / T3D_SHARDS;
+    const size_t node_base = (size_t)level * rp.cap;
+    const int L = sc.n_lights;
+    // input: level 0 is the dense list of primary samples; deeper levels read this wave's shard of the queue
+    const int n_in = LEVEL0 ? rp.n0 : min(cnt->n_rays[level][shard].v, shard_cap);
+    int chunk = LEVEL0 ? gw : gw / T3D_SHARDS;                     // in units of 64 rays
+    const int chunk_step = LEVEL0 ? nw : nw / T3D_SHARDS;
+    int ring_nodes = 0;  // nodes appended to the ring so far      (wave-uniform)
+    int items_done = 0;  // (node, light) pairs already traced     (wave-uniform)
+    for (;;) {
+        const int pending = ring_nodes * L - items_done;
+        const bool more = (long long)chunk * 64 < n_in;
+        if (pending >= 128 || (!more && pending > 0)) {
+            // ---------------- shadow round: two pairs per lane (items lane and lane + 64) ----------------
+            V3 P[2], N[2];
+            float rough[2], I[2];
+            int l[2], gnode[2];
+            bool run[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int item = items_done + lane + 64 * r;
+                run[r] = item < ring_nodes * L;
+                const int it = run[r] ? item : items_done;
+                const int nd = it / L;
+                l[r] = it - nd * L;
+                const float4 ra = ring_a[wid][nd % T3D_RING], rb = ring_b[wid][nd % T3D_RING];
+                P[r] = mk(ra.x, ra.y, ra.z); N[r] = mk(rb.x, rb.y, rb.z); rough[r] = ra.w; gnode[r] = __float_as_int(rb.w);
+            }
+            shadow_items2(sc, tri_rows, spheres, P, N, rough, l, I);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                if (run[r]) pool.li[(node_base + (size_t)gnode[r]) * L + l[r]] = I[r];
+            items_done += pending < 128 ? pending : 128;
+        } else if (more) {
+            // ---------------- trace round ----------------
+            const int idx = chunk * 64 + lane;
+            const bool active = idx < n_in;
+            const int i = LEVEL0 ? idx : shard * shard_cap + idx;
+            V3 o = mk(0, 0, 0), d = mk(0, 0, 1), pstart = mk(0, 0, 0);
+            float ior = 1.0f;
+            int inside_obj = -1, parent = -1, side = 0;
+            uint32_t ps = 0, heap = 1;
+            int px = 0, py = 0, smp = 0;
+            if (active) {
+                if (LEVEL0) {
+                    ps = (uint32_t)i;
+                    parent = i;
+                } else {
+                    RayRec r = rays_in[i];
+                    o = mk(r.o.x, r.o.y, r.o.z); ior = r.o.w;
+                    d = mk(r.d.x, r.d.y, r.d.z); inside_obj = __float_as_int(r.d.w);
+                    pstart = mk(r.p.x, r.p.y, r.p.z); parent = __float_as_int(r.p.w);
+                    ps = r.k.x; heap = r.k.y; side = (int)r.k.z;
+                }
                 int pix = (int)ps / rp.samples;
                 smp = (int)ps - pix * rp.samples;
                 int ly = pix / rp.width;
                 px = pix - ly * rp.width;
                 py = rp.row0 + ly * rp.row_stride;
                 if (rp.single) { px = rp.px0; py = rp.py0; smp = rp.sample0; }
+                if (LEVEL0) camera_ray(sc.cam, rp, px, py, o, d);
             }
-        }
-        const bool lights = LEVEL0 ? (rp.lights != 0) : true;
-        const bool back_cull = (ior == 1.0f);  // T3DR.py:961
-        Hit h;
-        h.t = 0.0f; h.prim = -1; h.back = 0;
-        if (__any(active)) h = closest_hit(tri_rows, sc.n_tris, spheres, sc.n_spheres, o, d, lights, back_cull);  // wave-uniform
-        const bool hit = active && h.prim >= 0;
+            const bool lights = LEVEL0 ? (rp.lights != 0) : true;
+            const bool back_cull = (ior == 1.0f);  // T3DR.py:961
+            Hit h = closest_hit(tri_rows, sc.n_tris, spheres, sc.n_spheres, o, d, lights, back_cull);
+            const bool hit = active && h.prim >= 0;
 
-        // ---- classify ---------------------------------------------------------------------
-        V3 P = madd(o, d, h.t);
-        V3 N = mk(0, 0, 1);      // unit normal as used by bounce / transmit / direct light
-        V3 Nraw = mk(0, 0, 1);   // normal as the reference stores it (debug records)
-        int obj = -1, face = -1, shader = -1, dirflag = 0;
-        bool emitter = false;
-        V3 emit = mk(0, 0, 0);
-        float strength = 1.0f;
-        if (hit) {
-            if (h.prim < sc.n_tris) {
-                int4 meta = sc.tri_meta[h.prim];
-                float4 rn = tri_rows[3 * h.prim];
-                obj = meta.x; face = meta.y; shader = meta.z;
-                Nraw = mk(rn.x, rn.y, rn.z);
-                N = normalize(Nraw);
-                dirflag = (dot(Nraw, d) < 0.0f) ? 0 : 1;
-                DevShader sh = sc.shaders[shader];
-                emitter = sh.emis > 0.0f;
-                strength = sh.emis;
-            } else {
-                DevSphere sp = spheres[h.prim - sc.n_tris];
-                obj = sp.obj; shader = sp.shader; dirflag = h.back;
-                N = normalize(mk(P.x - sp.cx, P.y - sp.cy, P.z - sp.cz));
-                Nraw = N;
-                emitter = sp.is_light != 0;
-                strength = sp.strength;
-            }
-            if (emitter) {
-                // computeColor for lights / emissive faces (T3DR.py:1014-1041): distance to the camera
-                DevShader sh = sc.shaders[shader];
-                V3 pc = mk(P.x - sc.cam.pos[0], P.y - sc.cam.pos[1], P.z - sc.cam.pos[2]);
-                float att = attenuation(dot(pc, pc));
-                emit = mk(fminf(sh.r * strength * att, 255.0f), fminf(sh.g * strength * att, 255.0f),
-                          fminf(sh.b * strength * att, 255.0f));
-            }
-        }
-        if (LEVEL0 && active) {
-            if (smp == 0 || rp.single) {
-                int pix = rp.single ? 0 : i / rp.samples;
-                if (out.primary) { out.primary[2 * pix] = obj; out.primary[2 * pix + 1] = face; }
-                if (out.primary_t) out.primary_t[pix] = hit ? h.t : __builtin_nanf("");
-            }
-        }
-        // attenuation of this node's colour on its way into the parent: |P - parent.ray.start|
-        V3 pp = P - pstart;
-        const float att_parent = LEVEL0 ? 1.0f : attenuation(dot(pp, pp));
-
-        // ---- debug record (single-pixel mode) ----------------------------------------------
-        int dbg_idx = -1;
-        if (rp.want_debug && hit) {
-            dbg_idx = atomicAdd(&cnt->n_dbg, 1);
-            if (dbg_idx < out.dbg_cap) {
-                t3d_node& nd = out.dbg[dbg_idx];
-                nd.heap = (int)heap; nd.obj = obj; nd.face = face; nd.direction = dirflag; nd.t = h.t;
-                nd.point[0] = P.x; nd.point[1] = P.y; nd.point[2] = P.z;
-                nd.normal[0] = Nraw.x; nd.normal[1] = Nraw.y; nd.normal[2] = Nraw.z;
-                nd.ray_start[0] = o.x; nd.ray_start[1] = o.y; nd.ray_start[2] = o.z;
-                nd.ray_dir[0] = d.x; nd.ray_dir[1] = d.y; nd.ray_dir[2] = d.z;
-                nd.ray_ior = ior; nd.ray_obj = inside_obj;
-                nd.color[0] = emit.x; nd.color[1] = emit.y; nd.color[2] = emit.z;
-            }
-        }
-
-        // ---- leaves -------------------------------------------------------------------------
-        if (active && (!hit || emitter)) {
-            if (LEVEL0) {
-                V3 c = hit ? emit : mk(rp.ambient[0], rp.ambient[1], rp.ambient[2]);  // T3DR.py:1006-1007
-                out.sample_color[i] = make_float4(c.x, c.y, c.z, 0.0f);
-            } else if (hit) {
-                float4* slot = side ? pool.d : pool.c;
-                float4 cur = slot[parent];
-                cur.x = emit.x * att_parent; cur.y = emit.y * att_parent; cur.z = emit.z * att_parent;
-                slot[parent] = cur;
-            }
-        }
-
-        // ---- shaded node: what it is and which children it spawns ------------------------------------
-        const bool shaded = hit && !emitter;
-        // ---- children (T3DR.py:979-995) --------------------------------------------------------
-        bool want_t = false, want_b = false;
-        V3 tdir = mk(0, 0, 1), bdir = mk(0, 0, 1), tstart = P, bstart = P;
-        float t_ior = 1.0f;
-        int t_obj = -1;
-        if (shaded && level < rp.bounces) {
-            DevShader sh = sc.shaders[shader];
-            float refl = sh.refl, rough = sh.rough;
-            if (refl != 1.0f) {
-                // transmit (T3DR.py:904-956)
-                V3 Nn = N;
-                float n2 = sc.obj_ior[obj];
-                int nobj = obj;
-                if (obj == inside_obj) { Nn = N * -1.0f; n2 = 1.0f; nobj = -1; }
-                float cosI = -dot(d, Nn);
-                float ratio = ior / n2;
-                float sin2T = ratio * ratio * (1.0f - cosI * cosI);
-                if (!(sin2T > 1.0f)) {
-                    float cosT = __builtin_sqrtf(1.0f - sin2T);
-                    V3 spec = madd(d * ratio, Nn, ratio * cosI - cosT);
-                    V3 diff = normalize(keyed_cube(rp.seed, (uint32_t)px, (uint32_t)py, (uint32_t)smp, 2u * heap + 1u));
-                    if (dot(diff, Nn) > 0.0f) diff = diff * -1.0f;
-                    V3 dir = madd(spec * (1.0f - rough), diff, rough);
-                    tstart = madd(P, dir, 0.1f);
-                    tdir = normalize(dir);
-                    t_ior = n2; t_obj = nobj;
-                    want_t = true;
-                }
-            }
-            if (refl != 0.0f) {
-                // bounce (T3DR.py:733-759)
-                V3 diff = normalize(keyed_cube(rp.seed, (uint32_t)px, (uint32_t)py, (uint32_t)smp, 2u * heap));
-                if (dot(diff, N) < 0.0f) diff = diff * -1.0f;
-                V3 spec = madd(d, N, -2.0f * dot(d, N));
-                V3 dir = madd(spec * (1.0f - rough), diff, rough);
-                bstart = madd(P, dir, 0.1f);
-                bdir = normalize(dir);
-                want_b = true;
-            }
-        }
-        // ---- block-aggregated append: node slot and child-ray slots ------------------------------------
-        const unsigned long long m_n = __ballot(shaded), m_t = __ballot(want_t), m_b = __ballot(want_b);
-        if (lane == 0) { s_cnt[wid][0] = __popcll(m_n); s_cnt[wid][1] = __popcll(m_t); s_cnt[wid][2] = __popcll(m_b); }
-        __syncthreads();
-        if (threadIdx.x == 0) {           // wave 0 reserves node slots, wave 1 child-ray slots: the two atomics overlap
-            int tn = 0;
-            for (int w = 0; w < T3D_TRACE_BLOCK / 64; ++w) tn += s_cnt[w][0];
-            s_base[0] = tn ? atomicAdd(&cnt->n_nodes[level], tn) : 0;
-        } else if (threadIdx.x == 64) {
-            int tr = 0;
-            for (int w = 0; w < T3D_TRACE_BLOCK / 64; ++w) tr += s_cnt[w][1] + s_cnt[w][2];
-            s_base[1] = tr ? atomicAdd(&cnt->n_rays[level + 1], tr) : 0;
-        }
-        __syncthreads();
-        int node = s_base[0], rbase = s_base[1];
-        for (int w = 0; w < wid; ++w) { node += s_cnt[w][0]; rbase += s_cnt[w][1] + s_cnt[w][2]; }
-        node += __popcll(m_n & lt_mask);
-        const int ti = rbase + __popcll(m_t & lt_mask);
-        const int bi = rbase + s_cnt[wid][1] + __popcll(m_b & lt_mask);
-        __syncthreads();  // s_cnt / s_base are rewritten by the next chunk
-
-        const bool stored = shaded && node < rp.cap;
-        if (shaded && !stored) cnt->overflow = 1;
-        if (stored) {
-            const float k = 2.0f / 255.0f;  // absent children count as ambient * 2/255 (T3DR.py:1054-1055)
-            size_t g = node_base + (size_t)node;
-            pool.a[g] = make_float4(P.x, P.y, P.z, att_parent);
-            pool.b[g] = make_float4(N.x, N.y, N.z, __int_as_float(shader | (side << 30)));
-            pool.c[g] = make_float4(rp.ambient[0] * k, rp.ambient[1] * k, rp.ambient[2] * k, __int_as_float(parent));
-            pool.d[g] = make_float4(rp.ambient[0] * k, rp.ambient[1] * k, rp.ambient[2] * k, 0.0f);
-            if (rp.want_debug) pool.dbg[g] = dbg_idx;
-        }
-        if (want_t && stored) {
-            if (ti < rp.cap) {
-                RayRec r;
-                r.o = make_float4(tstart.x, tstart.y, tstart.z, t_ior);
-                r.d = make_float4(tdir.x, tdir.y, tdir.z, __int_as_float(t_obj));
-                r.p = make_float4(o.x, o.y, o.z, __int_as_float((int)(node_base + node)));
-                r.k = make_uint4(ps, 2u * heap + 1u, 1u, (uint32_t)dbg_idx);
-                rays_out[ti] = r;
-            } else cnt->overflow = 1;
-        }
-        if (want_b && stored) {
-            if (bi < rp.cap) {
-                RayRec r;
-                r.o = make_float4(bstart.x, bstart.y, bstart.z, ior);
-                r.d = make_float4(bdir.x, bdir.y, bdir.z, __int_as_float(inside_obj));
-                r.p = make_float4(o.x, o.y, o.z, __int_as_float((int)(node_base + node)));
-                r.k = make_uint4(ps, 2u * heap, 0u, (uint32_t)dbg_idx);
-                rays_out[bi] = r;
-            } else cnt->overflow = 1;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_shade: getDirectLight (T3DR.py:820-900) + getVisibility (T3DR.py:762-778) for one level's nodes
-// ------------------------------------------------------------------------------------------------
-#ifndef T3D_SHADE_NR
-#define T3D_SHADE_NR 2
-#endif
-// Work item p = (node p / L, light p % L); every lane takes T3D_SHADE_NR consecutive items and traces
-// their shadow rays together.  The intensity of item p goes to light_i[p]; k_resolve adds the L values
-// of a node in light order, as getDirectLight does.
-__global__ __launch_bounds__(T3D_BLOCK) void k_shade(DevScene sc, const float4* __restrict__ tri_rows,
-                                                     const DevSphere* __restrict__ spheres, RenderParams rp, int level,
-                                                     NodePool pool, const Counters* __restrict__ cnt) {
-    constexpr int NR = T3D_SHADE_NR;
-    const int L = sc.n_lights;
-    const long long n_items = (long long)min(cnt->n_nodes[level], rp.cap) * L;
-    const long long stride = (long long)gridDim.x * blockDim.x * NR;
-    const size_t node_base = (size_t)level * rp.cap;
-    const V3 cam = mk(sc.cam.pos[0], sc.cam.pos[1], sc.cam.pos[2]);
-    for (long long first = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * NR; ; first += stride) {
-        if (!__any(first < n_items)) break;  // whole wave past the end (wave-uniform)
-        V3 o[NR], d[NR], N[NR], view[NR];
-        bool cull[NR];
-        float dist2[NR], rough[NR], strength[NR];
-        bool active[NR];
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const long long p = first + r;
-            active[r] = p < n_items;
-            const long long pp = active[r] ? p : 0;
-            const int j = (int)(pp / L), l = (int)(pp - (long long)j * L);
-            const size_t g = node_base + (size_t)j;
-            const float4 a = pool.a[g], b = pool.b[g];
-            const V3 P = mk(a.x, a.y, a.z);
-            N[r] = mk(b.x, b.y, b.z);
-            rough[r] = sc.shaders[__float_as_int(b.w) & 0x3FFFFFFF].rough;
-            view[r] = normalize(cam - P);
-            const DevLight lt = sc.lights[l];
-            const V3 to = mk(lt.x - P.x, lt.y - P.y, lt.z - P.z);
-            dist2[r] = dot(to, to);
-            d[r] = to * __builtin_amdgcn_rsqf(dist2[r]);
-            o[r] = madd(P, d[r], 0.2f);
-            strength[r] = lt.strength;
-            cull[r] = false;
-        }
-        Hit h[NR];
-        closest_hit_n<NR>(tri_rows, sc.n_tris, spheres, sc.n_spheres, o, d, true, cull, h);
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            float vis = 1.0f;
-            if (h[r].prim >= 0) {
-                if (h[r].prim < sc.n_tris) {
-                    DevShader bs = sc.shaders[sc.tri_meta[h[r].prim].z];
-                    if (!(bs.emis > 0.0f)) vis = 1.0f - bs.refl;
+            // ---- classify ---------------------------------------------------------------------
+            V3 P = madd(o, d, h.t);
+            V3 N = mk(0, 0, 1);      // unit normal as used by bounce / transmit / direct light
+            V3 Nraw = mk(0, 0, 1);   // normal as the reference stores it (debug records)
+            int obj = -1, face = -1, shader = -1, dirflag = 0;
+            bool emitter = false;
+            V3 emit = mk(0, 0, 0);
+            float strength = 1.0f;
+            if (hit) {
+                if (h.prim < sc.n_tris) {
+                    int4 meta = sc.tri_meta[h.prim];
+                    float4 rn = tri_rows[3 * h.prim];
+                    obj = meta.x; face = meta.y; shader = meta.z;
+                    Nraw = mk(rn.x, rn.y, rn.z);
+                    N = normalize(Nraw);
+                    dirflag = (dot(Nraw, d) < 0.0f) ? 0 : 1;
+                    DevShader sh = sc.shaders[shader];
+                    emitter = sh.emis > 0.0f;
+                    strength = sh.emis;
                 } else {
-                    DevSphere sp = spheres[h[r].prim - sc.n_tris];
-                    if (!sp.is_light) vis = 1.0f - sc.shaders[sp.shader].refl;
+                    DevSphere sp = spheres[h.prim - sc.n_tris];
+                    obj = sp.obj; shader = sp.shader; dirflag = h.back;
+                    N = normalize(mk(P.x - sp.cx, P.y - sp.cy, P.z - sp.cz));
+                    Nraw = N;
+                    emitter = sp.is_light != 0;
+                    strength = sp.strength;
+                }
+                if (emitter) {
+                    // computeColor for lights / emissive faces (T3DR.py:1014-1041): distance to the camera
+                    DevShader sh = sc.shaders[shader];
+                    V3 pc = mk(P.x - sc.cam.pos[0], P.y - sc.cam.pos[1], P.z - sc.cam.pos[2]);
+                    float att = attenuation(dot(pc, pc));
+                    emit = mk(fminf(sh.r * strength * att, 255.0f), fminf(sh.g * strength * att, 255.0f),
+                              fminf(sh.b * strength * att, 255.0f));
                 }
             }
-            float ldn = dot(d[r], N[r]);
-            float diffuse = fmaxf(0.0f, ldn);
-            V3 R = madd(d[r] * -1.0f, N[r], 2.0f * ldn);
-            float spec = (dot(normalize(R), view[r]) < 0.96f) ? 0.0f : 1.0f;
-            float att = attenuation(dist2[r]);
-            float I = (diffuse * rough[r] + spec * (1.0f - rough[r])) * strength[r] * vis * att;
-            if (active[r]) pool.li[node_base * L + (size_t)(first + r)] = I;
+            if (LEVEL0 && active) {
+                if (smp == 0 || rp.single) {
+                    int pix = rp.single ? 0 : i / rp.samples;
+                    if (out.primary) { out.primary[2 * pix] = obj; out.primary[2 * pix + 1] = face; }
+                    if (out.primary_t) out.primary_t[pix] = hit ? h.t : __builtin_nanf("");
+                }
+            }
+            // attenuation of this node's colour on its way into the parent: |P - parent.ray.start|
+            V3 pp = P - pstart;
+            const float att_parent = LEVEL0 ? 1.0f : attenuation(dot(pp, pp));
+
+            // ---- debug record (single-pixel mode) ----------------------------------------------
+            int dbg_idx = -1;
+            if (rp.want_debug && hit) {
+                dbg_idx = atomicAdd(&cnt->n_dbg, 1);
+                if (dbg_idx < out.dbg_cap) {
+                    t3d_node& nd = out.dbg[dbg_idx];
+                    nd.heap = (int)heap; nd.obj = obj; nd.face = face; nd.direction = dirflag; nd.t = h.t;
+                    nd.point[0] = P.x; nd.point[1] = P.y; nd.point[2] = P.z;
+                    nd.normal[0] = Nraw.x; nd.normal[1] = Nraw.y; nd.normal[2] = Nraw.z;
+                    nd.ray_start[0] = o.x; nd.ray_start[1] = o.y; nd.ray_start[2] = o.z;
+                    nd.ray_dir[0] = d.x; nd.ray_dir[1] = d.y; nd.ray_dir[2] = d.z;
+                    nd.ray_ior = ior; nd.ray_obj = inside_obj;
+                    nd.color[0] = emit.x; nd.color[1] = emit.y; nd.color[2] = emit.z;
+                }
+            }
+
+            // ---- leaves -------------------------------------------------------------------------
+            if (active && (!hit || emitter)) {
+                if (LEVEL0) {
+                    V3 c = hit ? emit : mk(rp.ambient[0], rp.ambient[1], rp.ambient[2]);  // T3DR.py:1006-1007
+                    out.sample_color[i] = make_float4(c.x, c.y, c.z, 0.0f);
+                } else if (hit) {
+                    float4* slot = side ? pool.d : pool.c;
+                    float4 cur = slot[parent];
+                    cur.x = emit.x * att_parent; cur.y = emit.y * att_parent; cur.z = emit.z * att_parent;
+                    slot[parent] = cur;
+                }
+            }
+
+            // ---- shaded node: what it is and which children it spawns ------------------------------------
+            const bool shaded = hit && !emitter;
+            // ---- children (T3DR.py:979-995) --------------------------------------------------------
+            bool want_t = false, want_b = false;
+            V3 tdir = mk(0, 0, 1), bdir = mk(0, 0, 1), tstart = P, bstart = P;
+            float t_ior = 1.0f;
+            int t_obj = -1;
+            if (shaded && level < rp.bounces) {
+                DevShader sh = sc.shaders[shader];
+                float refl = sh.refl, rough = sh.rough;
+                if (refl != 1.0f) {
+                    // transmit (T3DR.py:904-956)
+                    V3 Nn = N;
+                    float n2 = sc.obj_ior[obj];
+                    int nobj = obj;
+                    if (obj == inside_obj) { Nn = N * -1.0f; n2 = 1.0f; nobj = -1; }
+                    float cosI = -dot(d, Nn);
+                    float ratio = ior / n2;
+                    float sin2T = ratio * ratio * (1.0f - cosI * cosI);
+                    if (!(sin2T > 1.0f)) {
+                        float cosT = __builtin_sqrtf(1.0f - sin2T);
+                        V3 spec = madd(d * ratio, Nn, ratio * cosI - cosT);
+                        V3 diff = normalize(keyed_cube(rp.seed, (uint32_t)px, (uint32_t)py, (uint32_t)smp, 2u * heap + 1u));
+                        if (dot(diff, Nn) > 0.0f) diff = diff * -1.0f;
+                        V3 dir = madd(spec * (1.0f - rough), diff, rough);
+                        tstart = madd(P, dir, 0.1f);
+                        tdir = normalize(dir);
+                        t_ior = n2; t_obj = nobj;
+                        want_t = true;
+                    }
+                }
+                if (refl != 0.0f) {
+                    // bounce (T3DR.py:733-759)
+                    V3 diff = normalize(keyed_cube(rp.seed, (uint32_t)px, (uint32_t)py, (uint32_t)smp, 2u * heap));
+                    if (dot(diff, N) < 0.0f) diff = diff * -1.0f;
+                    V3 spec = madd(d, N, -2.0f * dot(d, N));
+                    V3 dir = madd(spec * (1.0f - rough), diff, rough);
+                    bstart = madd(P, dir, 0.1f);
+                    bdir = normalize(dir);
+                    want_b = true;
+                }
+            }
+            // ---- append: node slot and child-ray slots (wave64 ballot + prefix popcount) --------------------
+            const unsigned long long m_n = __ballot(shaded), m_t = __ballot(want_t), m_b = __ballot(want_b);
+            const int c_n = __popcll(m_n), c_t = __popcll(m_t), c_b = __popcll(m_b);
+            int base_n = 0, base_r = 0;
+            if (lane == 0) {   // both atomics are issued before either result is needed
+                if (c_n) base_n = atomicAdd(&cnt->n_nodes[level][shard].v, c_n);
+                if (c_t + c_b) base_r = atomicAdd(&cnt->n_rays[level + 1][shard].v, c_t + c_b);
+            }
+            base_n = __shfl(base_n, 0);
+            base_r = __shfl(base_r, 0);
+            const int nloc = base_n + __popcll(m_n & lt_mask);          // index within the shard
+            const int tloc = base_r + __popcll(m_t & lt_mask);
+            const int bloc = base_r + c_t + __popcll(m_b & lt_mask);
+            const int node = shard * shard_cap + nloc;                  // index within the level
+            const bool stored = shaded && nloc < shard_cap;
+            if (shaded && !stored) cnt->overflow = 1;
+            if (stored) {
+                const float k = 2.0f / 255.0f;  // absent children count as ambient * 2/255 (T3DR.py:1054-1055)
+                size_t g = node_base + (size_t)node;
+                pool.a[g] = make_float4(P.x, P.y, P.z, att_parent);
+                pool.b[g] = make_float4(N.x, N.y, N.z, __int_as_float(shader | (side << 30)));
+                pool.c[g] = make_float4(rp.ambient[0] * k, rp.ambient[1] * k, rp.ambient[2] * k, __int_as_float(parent));
+                pool.d[g] = make_float4(rp.ambient[0] * k, rp.ambient[1] * k, rp.ambient[2] * k, 0.0f);
+                if (rp.want_debug) pool.dbg[g] = dbg_idx;
+            }
+            if (want_t && stored) {
+                if (tloc < shard_cap) {
+                    RayRec r;
+                    r.o = make_float4(tstart.x, tstart.y, tstart.z, t_ior);
+                    r.d = make_float4(tdir.x, tdir.y, tdir.z, __int_as_float(t_obj));
+                    r.p = make_float4(o.x, o.y, o.z, __int_as_float((int)(node_base + node)));
+                    r.k = make_uint4(ps, 2u * heap + 1u, 1u, (uint32_t)dbg_idx);
+                    rays_out[shard * shard_cap + tloc] = r;
+                } else cnt->overflow = 1;
+            }
+            if (want_b && stored) {
+                if (bloc < shard_cap) {
+                    RayRec r;
+                    r.o = make_float4(bstart.x, bstart.y, bstart.z, ior);
+                    r.d = make_float4(bdir.x, bdir.y, bdir.z, __int_as_float(inside_obj));
+                    r.p = make_float4(o.x, o.y, o.z, __int_as_float((int)(node_base + node)));
+                    r.k = make_uint4(ps, 2u * heap, 0u, (uint32_t)dbg_idx);
+                    rays_out[shard * shard_cap + bloc] = r;
+                } else cnt->overflow = 1;
+            }
+            // shaded nodes enter the wave's ring in lane order
+            if (shaded && L > 0) {
+                const int slot = (ring_nodes + __popcll(m_n & lt_mask)) % T3D_RING;
+                ring_a[wid][slot] = make_float4(P.x, P.y, P.z, sc.shaders[shader].rough);
+                ring_b[wid][slot] = make_float4(N.x, N.y, N.z, __int_as_float(stored ? node : 0));
+            }
+            ring_nodes += c_n;
+            chunk += chunk_step;
+            // the ring is private to this wave; LDS operations of one wave complete in order, the fence
+            // only stops the compiler from moving the next round's reads above these writes
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            break;
         }
     }
 }
@@ -583,10 +683,14 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_shade(DevScene sc, const float4* 
 __global__ __launch_bounds__(T3D_BLOCK) void k_resolve(DevScene sc, RenderParams rp, int level, NodePool pool,
                                                        const Counters* __restrict__ cnt, float4* sample_color,
                                                        t3d_node* dbg, int dbg_cap) {
-    const int n = min(cnt->n_nodes[level], rp.cap);
     const size_t node_base = (size_t)level * rp.cap;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const size_t g = node_base + (size_t)i;
+    const int shard_cap = rp.cap / T3D_SHARDS;
+    const int lane = threadIdx.x & 63;
+    const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;  // nw: multiple of T3D_SHARDS
+    const int shard = gw % T3D_SHARDS;
+    const int n = min(cnt->n_nodes[level][shard].v, shard_cap);
+    for (int k = (gw / T3D_SHARDS) * 64 + lane; k < n; k += (nw / T3D_SHARDS) * 64) {
+        const size_t g = node_base + (size_t)shard * shard_cap + (size_t)k;
         float4 a = pool.a[g], b = pool.b[g], c = pool.c[g], d = pool.d[g];
         int meta = __float_as_int(b.w);
         int shader = meta & 0x3FFFFFFF, side = (meta >> 30) & 1;
@@ -679,7 +783,7 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_closest(DevScene sc, const float4
 struct t3d_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[2 * (T3D_MAX_BOUNCES + 1) + 4] = {};
+    hipEvent_t ev[(T3D_MAX_BOUNCES + 1) + 4] = {};
     std::string err;
     bool has_scene = false;
     int n_sm = 256;
@@ -906,20 +1010,24 @@ static int check_opts(t3d_ctx* c, const t3d_opts* o, int row0, int nrows) {
 // Counters and event timings of the most recent band; the stream must have been synchronised.
 static void fill_stats(t3d_ctx* c, t3d_stats* stats) {
     const int levels = c->last_levels;
-    const int n_ev = 2 * levels + 2;
+    const int n_ev = levels + 2;
     float ms = 0;
     hipEventElapsedTime(&ms, c->ev[0], c->ev[n_ev - 1]);
     stats->ms_device += ms;
     for (int d = 0; d < levels; ++d) {
-        hipEventElapsedTime(&ms, c->ev[2 * d], c->ev[2 * d + 1]);
-        stats->ms_k_trace += ms;
-        hipEventElapsedTime(&ms, c->ev[2 * d + 1], c->ev[2 * d + 2]);
-        stats->ms_k_shade += ms;
+        hipEventElapsedTime(&ms, c->ev[d], c->ev[d + 1]);
+        stats->ms_k_level += ms;
     }
-    hipEventElapsedTime(&ms, c->ev[2 * levels], c->ev[n_ev - 1]);
+    hipEventElapsedTime(&ms, c->ev[levels], c->ev[n_ev - 1]);
     stats->ms_resolve += ms;
     uint64_t rays = 0, nodes = 0;
-    for (int d = 0; d < levels; ++d) { rays += d == 0 ? c->last_n0 : (uint64_t)c->h_cnt->n_rays[d]; nodes += (uint64_t)c->h_cnt->n_nodes[d]; }
+    for (int d = 0; d < levels; ++d) {
+        if (d == 0) rays += c->last_n0;
+        for (int sh = 0; sh < T3D_SHARDS; ++sh) {
+            if (d > 0) rays += (uint64_t)c->h_cnt->n_rays[d][sh].v;
+            nodes += (uint64_t)c->h_cnt->n_nodes[d][sh].v;
+        }
+    }
     uint64_t shadow = nodes * (uint64_t)c->sc.n_lights;
     uint64_t q = rays + shadow;
     stats->rays_api += c->last_n0 + shadow;
@@ -930,8 +1038,7 @@ static void fill_stats(t3d_ctx* c, t3d_stats* stats) {
     stats->sphere_tests += q * (uint64_t)c->sc.n_spheres - (c->last_lights ? 0 : c->last_n0 * (uint64_t)c->n_light_objs);
     stats->nodes += nodes;  // shaded nodes only; emitter leaves are folded into their parents
     stats->launches += c->last_launches;
-    stats->n_k_trace += (uint64_t)levels;
-    stats->n_k_shade += (uint64_t)levels;
+    stats->n_k_level += (uint64_t)levels;
 }
 
 // Trace one band whose outputs are device pointers.  Returns T3D_E_CAPACITY if a level overflowed
@@ -943,7 +1050,8 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
     const size_t n0 = single ? 1 : (size_t)nrows * o->width * S;
     const int levels = o->bounces + 1;
     size_t cap = n0 * (size_t)cap_factor;
-    if (cap < 1024) cap = 1024;
+    if (cap < 64 * 1024) cap = 64 * 1024;   // at least 1024 entries per queue shard
+    cap = (cap + (size_t)T3D_SHARDS * 64 - 1) / ((size_t)T3D_SHARDS * 64) * ((size_t)T3D_SHARDS * 64);
     if (cap * (size_t)levels > (size_t)0x7FFFFFF0) { c->err = "band too large for 32-bit node indices"; return T3D_E_CAPACITY; }
     int rc = ensure_work(c, cap, levels, n0, single != nullptr);
     if (rc) return rc;
@@ -961,9 +1069,16 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
     TraceOut out{c->d_sample_color, d_prim, d_prim_t, d_dbg, dbg_cap};
     const int max_blocks = c->n_sm * 8;
     auto blocks_for = [&](size_t n) { size_t b = (n + T3D_BLOCK - 1) / T3D_BLOCK; return (int)(b < 1 ? 1 : (b > (size_t)max_blocks ? (size_t)max_blocks : b)); };
-    auto trace_blocks_for = [&](size_t n) { size_t b = (n + T3D_TRACE_BLOCK - 1) / T3D_TRACE_BLOCK; size_t mx = (size_t)c->n_sm * (2048 / T3D_TRACE_BLOCK); return (int)(b < 1 ? 1 : (b > mx ? mx : b)); };
+    // grids of the sharded kernels hold a multiple of T3D_SHARDS waves
+    const size_t grid_unit = T3D_SHARDS / (T3D_TRACE_BLOCK / 64);
+    auto trace_blocks_for = [&](size_t n) {
+        size_t b = (n + T3D_TRACE_BLOCK - 1) / T3D_TRACE_BLOCK, mx = (size_t)c->n_sm * (2048 / T3D_TRACE_BLOCK);
+        b = b > mx ? mx : b;
+        b = (b + grid_unit - 1) / grid_unit * grid_unit;
+        return (int)b;
+    };
     uint64_t launches = 0;
-    // per-launch timing: event 2d+1 after k_trace(d), 2d+2 after k_shade(d); read by fill_stats
+    // per-launch timing: event d+1 after k_level(d); read by fill_stats
     int n_timed = 0;
     auto tick = [&]() -> hipError_t { return hipEventRecord(c->ev[n_timed++], st); };
     const float4* rows = (const float4*)c->d_tri_rows;
@@ -973,16 +1088,14 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
         RayRec* in = c->d_rays[d & 1];
         RayRec* outq = c->d_rays[(d + 1) & 1];
         if (d == 0)
-            hipLaunchKernelGGL(k_trace<true>, dim3(trace_blocks_for(n0)), dim3(T3D_TRACE_BLOCK), 0, st, c->sc, rows, sph, rp, d, in, outq, c->pool, c->d_cnt, out);
+            hipLaunchKernelGGL(k_level<true>, dim3(trace_blocks_for(n0)), dim3(T3D_TRACE_BLOCK), 0, st, c->sc, rows, sph, rp, d, in, outq, c->pool, c->d_cnt, out);
         else
-            hipLaunchKernelGGL(k_trace<false>, dim3(single ? 1 : trace_blocks_for(c->cap_alloc)), dim3(T3D_TRACE_BLOCK), 0, st, c->sc, rows, sph, rp, d, in, outq, c->pool, c->d_cnt, out);
-        HIPCHK(c, tick());  // ev[1 + 2d]: k_trace(d) done
-        hipLaunchKernelGGL(k_shade, dim3(single ? 1 : max_blocks), dim3(T3D_BLOCK), 0, st, c->sc, rows, sph, rp, d, c->pool, c->d_cnt);
-        HIPCHK(c, tick());  // ev[2 + 2d]: k_shade(d) done
-        launches += 2;
+            hipLaunchKernelGGL(k_level<false>, dim3(single ? (int)grid_unit : trace_blocks_for(c->cap_alloc)), dim3(T3D_TRACE_BLOCK), 0, st, c->sc, rows, sph, rp, d, in, outq, c->pool, c->d_cnt, out);
+        HIPCHK(c, tick());  // ev[1 + d]: k_level(d) done
+        launches += 1;
     }
     for (int d = levels - 1; d >= 0; --d) {
-        hipLaunchKernelGGL(k_resolve, dim3(single ? 1 : (d == 0 ? blocks_for(n0) : max_blocks)), dim3(T3D_BLOCK), 0, st, c->sc, rp, d, c->pool, c->d_cnt,
+        hipLaunchKernelGGL(k_resolve, dim3(single ? (int)grid_unit : trace_blocks_for(c->cap_alloc)), dim3(T3D_TRACE_BLOCK), 0, st, c->sc, rp, d, c->pool, c->d_cnt,
                            c->d_sample_color, d_dbg, dbg_cap);
         launches++;
     }
@@ -1041,8 +1154,8 @@ extern "C" int t3d_render_rows_device(t3d_ctx* c, const t3d_opts* o, int row0, i
             if (stats) {
                 uint64_t* dst = &stats->rays_api; const uint64_t* src = &band_stats.rays_api;
                 for (int k = 0; k < T3D_STATS_N_COUNTERS; ++k) dst[k] += src[k];
-                stats->ms_device += band_stats.ms_device; stats->ms_k_trace += band_stats.ms_k_trace;
-                stats->ms_k_shade += band_stats.ms_k_shade; stats->ms_resolve += band_stats.ms_resolve;
+                stats->ms_device += band_stats.ms_device; stats->ms_k_level += band_stats.ms_k_level;
+                stats->ms_resolve += band_stats.ms_resolve;
             }
             break;
         }
@@ -1104,7 +1217,8 @@ extern "C" int t3d_trace_pixel(t3d_ctx* c, const t3d_opts* o, int x, int y, int 
     single.px0 = x; single.py0 = y; single.sample0 = sample;
     t3d_stats st{};
     // capacity factor: a single sample can branch at every level
-    int factor = worst < 1024 ? 1 : (worst + 1023) / 1024;
+    // all nodes of a single-pixel tree land in one queue shard: a shard must hold a full level (2^bounces rays)
+    int factor = T3D_SHARDS * (1 << o->bounces);
     rc = render_band(c, o, y, 1, factor, nullptr, nullptr, nullptr, nullptr, c->stream, &st, &single, d_dbg, dbg_cap);
     int n = 0;
     if (!rc) {

@@ -52,8 +52,8 @@ class Opts(C.Structure):
 class Stats(C.Structure):
     """ctypes mirror of ``t3d_stats``."""
     _fields_ = [(n, C.c_uint64) for n in ("rays_api", "queries", "trace_queries", "shadow_queries", "tri_tests",
-                                          "sphere_tests", "aabb_tests", "nodes", "launches", "n_k_trace", "n_k_shade")] + \
-               [(n, C.c_double) for n in ("ms_device", "ms_k_trace", "ms_k_shade", "ms_resolve")]
+                                          "sphere_tests", "aabb_tests", "nodes", "launches", "n_k_level")] + \
+               [(n, C.c_double) for n in ("ms_device", "ms_k_level", "ms_resolve")]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

@@ -17,5 +17,5 @@ python tools/prof_summary.py gpurun_out/prof_$tag/*/*_kernel_trace.csv
 python - <<PY
 import json
 d=json.load(open("gpurun_out/prof_${tag}_bench.json"))
-print("value", d["value"], "Mrays/s  ms/frame", d["ms_per_step"], " k_shade frac", d["roofline"]["frac"], " k_trace TF", d["roofline"]["k_trace"]["achieved"])
+print("value", d["value"], "Mrays/s  ms/frame", d["ms_per_step"], " k_level frac", d["roofline"]["frac"], "avg launch ms", d["roofline"]["avg_launch_ms"])
 PY
