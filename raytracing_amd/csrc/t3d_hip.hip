@@ -4,13 +4,14 @@
 // level by level of the trace tree (T3DR.py:959-1001):
 //
 //   for depth d = 0 .. bounces:
-//       k_level   per 256-thread block a scheduler over two kinds of closest-hit rounds:
-//                 trace round: one ray of level d per lane -- closest hit over all primitives, classify
+//       k_level   every wave is a small scheduler over two kinds of closest-hit rounds, two queries per
+//                 lane per round:
+//                 trace round: 128 rays of level d -- closest hit over all primitives, classify
 //                 (miss / emitter leaf / shaded node), append the node to the level's node array and the
 //                 reflected / transmitted child rays to the next level's queue (wave64 ballot + prefix
-//                 popcount, one atomic per counter per block);
-//                 shadow round: one (node, light) pair per lane from an LDS ring of the block's shaded
-//                 nodes -- shadow-ray closest hit, direct-light intensity (T3DR.py:820-900)
+//                 popcount, one atomic per counter per round, counters sharded 64 ways);
+//                 shadow round: 128 (node, light) pairs from an LDS ring of the wave's shaded nodes --
+//                 shadow-ray closest hit, direct-light intensity (T3DR.py:820-900)
 //   for depth d = bounces .. 0:
 //       k_resolve one thread per node: computeColor (T3DR.py:1004-1083) from the two child slots
 //                 and the direct light, pushes the colour into the parent's slot
@@ -19,12 +20,17 @@
 // The colour of a node is a clamped (non-linear) function of its children, so the tree is kept in
 // HBM and resolved bottom-up; a throughput-accumulating path tracer would not give the same image.
 //
-// All arithmetic is float32.  Triangles are tested through a per-triangle affine map prepared on
-// the host in float64 (plane row + two barycentric rows, 12 floats): t from the plane equation
-// like Ray.getTPlane (T3DE.py:133-142), then u, v of the hit point; the strict interior test of
-// Photon.pointWithinTriangle (T3DR.py:601-621) becomes u > 0, v > 0, u + v < 1.
-// Triangle rows are read with wave-uniform addresses, so they travel through the scalar data path
-// (SGPR operands) and cost no vector memory or LDS bandwidth.
+// All arithmetic is float32.  What bounds the closest-hit loop on gfx950 is vector-ALU ISSUE: a wave64
+// v_fma_f32 occupies its SIMD for ~4 cycles and so does a v_pk_fma_f32 doing two FMAs per lane (measured,
+// tools/ubench/valu_rate.hip), i.e. the FP32 vector peak is a packed-math peak.  Hence:
+//   * two rays per lane, held in the two halves of 64-bit register pairs, all dot products / hit points
+//     / barycentrics in packed instructions;
+//   * triangles grouped by supporting plane on the host: plane distance t and hit point P are computed
+//     once per plane (like Ray.getTPlane, T3DE.py:133-142), each triangle of the plane only adds its
+//     two barycentric rows u = a.P + aw, v = b.P + bw; the strict interior test of
+//     Photon.pointWithinTriangle (T3DR.py:601-621) becomes min3(u, v, 1-u-v) > 0;
+//   * plane and triangle rows are read with wave-uniform addresses, so they travel through the scalar
+//     data path (SGPR operands) and cost no vector memory or LDS bandwidth.
 #include <hip/hip_runtime.h>
 
 #include <math.h>
@@ -32,17 +38,19 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/t3d.h"
 
 #define T3D_BLOCK 256
-#ifndef T3D_TRACE_BLOCK
-#define T3D_TRACE_BLOCK 256 /* k_level block: one atomic per queue counter per 256 rays */
-#endif
+#define T3D_WAVES (T3D_BLOCK / 64)
 #define T3D_MAX_LIGHTS 64
 #define T3D_MAX_BOUNCES 14 /* heap index of the deepest node must fit 16 bits of the RNG key */
+#define T3D_SHARDS 64      /* queue shards per level; every launch holds a multiple of 64 waves */
+#define T3D_RING 256       /* nodes per wave: < 128 pairs pending before a trace round, which adds <= 128 nodes */
 
 // ------------------------------------------------------------------------------------------------
 // device-side scene
@@ -70,11 +78,20 @@ struct DevCamera {
     float zlen;
 };
 
+// Geometry streamed by every closest-hit query; passed as separate __restrict__ kernel arguments so
+// that the compiler may use scalar loads for it.
+//   planes      [G]   (n.xyz, n.v0) of the first triangle of each coplanar group, un-normalised like
+//                     MathematicalPlane.normal (T3DE.py:251-263)
+//   plane_first [G+1] triangle range of each group
+//   tri_uv      [2T]  per triangle (a.xyz, aw), (b.xyz, bw): P - v0 = u e1 + v e2, prepared in float64
+#define GEO_PARAMS const float4* __restrict__ planes, const int* __restrict__ plane_first, \
+                   const float4* __restrict__ tri_uv, const DevSphere* __restrict__ spheres
+#define GEO_ARGS planes, plane_first, tri_uv, spheres
+
 struct DevScene {
-    int n_tris, n_spheres, n_lights, n_shaders;
-    const float4* tri_rows;    // [3*T]: (n.xyz, n.v0), (a.xyz, aw), (b.xyz, bw)
-    const int4* tri_meta;      // [T]: (object, face-in-mesh, shader, unused)
-    const DevSphere* spheres;  // [S]
+    int n_planes, n_tris, n_spheres, n_lights, n_shaders;
+    const float4* tri_n;       // [T]: the triangle's own un-normalised normal (w unused)
+    const int4* tri_meta;      // [T]: (object, face-in-mesh, shader, unused); triangles in plane-group order
     const DevLight* lights;    // [L]
     const DevShader* shaders;  // [K]
     const float* obj_ior;      // [O]
@@ -88,7 +105,7 @@ struct RenderParams {
     uint32_t seed;
     float ambient[3];
     int n0;          // primary samples of this launch (rows * width * samples)
-    int cap;         // capacity of one level's ray queue / node array
+    int cap;         // capacity of one level's ray queue / node array (multiple of T3D_SHARDS * 64)
     int want_debug;  // record t3d_node entries (t3d_trace_pixel)
     int px0, py0, sample0;  // single-pixel mode (t3d_trace_pixel): the only pixel / sample traced
     int single;
@@ -99,7 +116,7 @@ struct RayRec {
     float4 o;  // origin, w = ior of the medium the ray travels in
     float4 d;  // unit direction, w = int bits: object the ray is inside (-1 none)
     float4 p;  // parent node's ray.start (attenuation origin, T3DR.py:1062-1064), w = int bits: parent node
-    uint4 k;   // x = pixel-sample index, y = heap index, z = side (0 = reflected slot, 1 = transmitted), w = debug parent
+    uint4 k;   // x = pixel-sample index, y = heap index, z = side (0 = reflected slot, 1 = transmitted), w = debug index
 };
 
 // Node arrays (structure of float4 arrays, 64 B per node in total)
@@ -107,12 +124,14 @@ struct NodePool {
     float4* a;  // P.xyz, attenuation towards the parent
     float4* b;  // unit normal, w = int bits: shader | side << 30
     float4* c;  // reflected slot rgb (child colour * attenuation), w = int bits: parent index
-    float4* d;  // transmitted slot rgb, w = direct-light intensity
+    float4* d;  // transmitted slot rgb
     int* dbg;   // debug record index of the node (only in single-pixel mode)
     float* li;  // [levels * cap * L] direct-light intensity per (node, light), written by k_level
 };
 
-#define T3D_SHARDS 64 /* queue shards per level; the launch's wave count is a multiple of it */
+// Queue counters.  Same-address device-scope atomics retire at roughly one per 7 ns on this chip, so one
+// counter per level would serialise the kernel: every level has T3D_SHARDS counters, each in its own
+// 64-byte line, and wave w only ever touches shard w % T3D_SHARDS.
 struct alignas(64) PaddedCount {
     int v;
     int pad[15];
@@ -139,12 +158,15 @@ __device__ __forceinline__ V3 madd(V3 a, V3 d, float t) {  // a + d * t
     return mk(fmaf(d.x, t, a.x), fmaf(d.y, t, a.y), fmaf(d.z, t, a.z));
 }
 __device__ __forceinline__ V3 normalize(V3 a) { return a * __builtin_amdgcn_rsqf(dot(a, a)); }
-__device__ __forceinline__ float length(V3 a) { return __builtin_sqrtf(dot(a, a)); }
 
 __device__ __forceinline__ float attenuation(float dist2) {  // getAttenuation(d), T3DR.py:782-785, from d^2
     float a = __builtin_amdgcn_rcpf(fmaf(0.01f, dist2, 1.0f));
     return fmaxf(0.0f, fminf(1.0f, a));
 }
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 splat(float s) { return (f2)(s); }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 // ------------------------------------------------------------------------------------------------
 // keyed random numbers (raytracing_amd/keyed_rng.py)
@@ -164,124 +186,63 @@ __device__ __forceinline__ V3 keyed_cube(uint32_t seed, uint32_t px, uint32_t py
 }
 
 // ------------------------------------------------------------------------------------------------
-// closest hit: Photon.getFirstCollision (T3DR.py:654-730) over every primitive
+// closest hit: Photon.getFirstCollision (T3DR.py:654-730) over every primitive, two rays per lane
 // ------------------------------------------------------------------------------------------------
 struct Hit {
     float t;
-    int prim;  // < 0 miss; [0, T) triangle; T + s sphere s
+    int prim;  // < 0 miss; [0, T) triangle (plane-group order); T + s sphere s
     int back;  // sphere: 1 = hit from inside
 };
 
-// NR rays per lane share every triangle row: the rows arrive through the scalar data path once per
-// triangle and wave, so testing several rays against them divides that traffic (and the scalar-load
-// waits) by NR.
-// cull_limit[r]: 0 when back faces are rejected for ray r (only d.n < 0 counts), +inf when both sides
-// count.  The decision logic is arithmetic (min3 + one compare) instead of a chain of compares:
-//   m  = min(u, v, 1-u-v, |d.n| - 1e-6, cull_limit - d.n)      inside, not parallel, facing
-//   tt = m > 0 ? t : +inf
-//   closer  <=>  bits(tt) < bits(best) as UNSIGNED integers: true exactly for 0 <= tt < best, false for
-//   negative, +inf and NaN values (their bit patterns are above every non-negative finite float)
-template <int NR>
-__device__ __forceinline__ void closest_hit_n(const float4* __restrict__ tri_rows, int n_tris,
-                                              const DevSphere* __restrict__ spheres, int n_spheres, const V3 (&o)[NR],
-                                              const V3 (&d)[NR], bool lights, const bool (&back_cull)[NR], Hit (&out)[NR]) {
+// Per plane group (getFaceCollision, T3DR.py:624-651):  d.n, t = (n.v0 - n.o) / (d.n), P = o + t d, and the
+// plane-level rejections folded into one value:
+//     pm = min((d.n)^2 - 1e-12, cull - d.n) > 0   <=>   |d.n| > 1e-6 and (d.n < 0 or both sides count)
+// (cull = 0 when back faces are rejected, +inf otherwise; packed instructions have no |x| modifier, hence
+// the square).  tp = pm > 0 ? t : +inf.
+// Per triangle of the group: u, v, w = 1-u-v; inside <=> min3(u, v, w) > 0 (strict: edges miss).
+// Distances are compared as UNSIGNED integer bit patterns: bits(tt) < bits(best) holds exactly for
+// 0 <= tt < best and fails for negative, +inf and NaN values, so "t >= 0" needs no test of its own.
+// Groups and triangles are visited so that the lowest original triangle index wins equal distances
+// (the reference keeps the first hit tested, T3DR.py:715).  A group whose plane cannot beat the current
+// best of any lane is skipped for the whole wave.
+__device__ __forceinline__ void closest_hit2(GEO_PARAMS, int n_planes, int n_tris, int n_spheres, V3 o0, V3 d0, V3 o1, V3 d1,
+                                             bool lights, bool back_cull0, bool back_cull1, Hit& out0, Hit& out1) {
     const uint32_t INF_BITS = 0x7f800000u;
-    uint32_t best[NR];
-    int prim[NR], back[NR];
-    float cull_limit[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) { best[r] = INF_BITS; prim[r] = -1; back[r] = 0; cull_limit[r] = back_cull[r] ? 0.0f : __builtin_inff(); }
-    // Triangles.  getFaceCollision (T3DR.py:624-651): reject |d.n| < 1e-6, t = (n.v0 - n.o) / (n.d),
-    // reject t < 0, strict interior test, back faces rejected when back_cull.  First hit wins ties.
-    for (int i = 0; i < n_tris; ++i) {
-        const float4 rn = tri_rows[3 * i + 0];
-        const float4 ra = tri_rows[3 * i + 1];
-        const float4 rb = tri_rows[3 * i + 2];
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            float dn = fmaf(rn.z, d[r].z, fmaf(rn.y, d[r].y, rn.x * d[r].x));
-            float q = fmaf(rn.z, o[r].z, fmaf(rn.y, o[r].y, fmaf(rn.x, o[r].x, -rn.w)));  // n.o - n.v0
-            float t = -q * __builtin_amdgcn_rcpf(dn);
-            float px = fmaf(d[r].x, t, o[r].x), py = fmaf(d[r].y, t, o[r].y), pz = fmaf(d[r].z, t, o[r].z);
-            float u = fmaf(ra.z, pz, fmaf(ra.y, py, fmaf(ra.x, px, ra.w)));
-            float v = fmaf(rb.z, pz, fmaf(rb.y, py, fmaf(rb.x, px, rb.w)));
-            float w = (1.0f - u) - v;
-            float m = fminf(fminf(u, v), w);
-            m = fminf(fminf(m, __builtin_fabsf(dn) - 1e-6f), cull_limit[r] - dn);
-            uint32_t tt = (m > 0.0f) ? __float_as_uint(t) : INF_BITS;
-            bool closer = tt < best[r];
-            best[r] = closer ? tt : best[r];
-            prim[r] = closer ? i : prim[r];
-        }
-    }
-    // Spheres and lights.  getSphereCollision (T3DR.py:572-598), Ray.getTSphere (T3DE.py:145-163).
-    for (int s = 0; s < n_spheres; ++s) {
-        const DevSphere sp = spheres[s];
-        if (sp.is_light && !lights) continue;  // wave-uniform
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            V3 L = mk(o[r].x - sp.cx, o[r].y - sp.cy, o[r].z - sp.cz);
-            float b = dot(L, d[r]);
-            float c = dot(L, L) - sp.r2;
-            float disc = fmaf(b, b, -c);
-            float root = __builtin_sqrtf(fmaxf(disc, 0.0f));
-            float t1 = -b - root, t2 = -b + root;
-            bool front = t1 > 0.0f;
-            bool inside = (!front) & (t2 > 0.0f) & (!back_cull[r]) & (sp.is_light == 0);
-            float t = front ? t1 : t2;
-            bool ok = (disc >= 0.0f) & (front | inside);
-            uint32_t tt = ok ? __float_as_uint(t) : INF_BITS;
-            bool closer = tt < best[r];
-            best[r] = closer ? tt : best[r];
-            prim[r] = closer ? n_tris + s : prim[r];
-            back[r] = closer ? (front ? 0 : 1) : back[r];
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < NR; ++r) { out[r].t = __uint_as_float(best[r]); out[r].prim = prim[r]; out[r].back = back[r]; }
-}
-
-// Two rays per lane in PACKED float32: on gfx950 a wave64 v_fma_f32 occupies its SIMD for 4 cycles, and so
-// does a v_pk_fma_f32 that does two FMAs per lane -- the FP32 vector peak (157 TFLOP/s) is a packed-math
-// peak.  The two rays of a lane sit in the two halves of 64-bit register pairs; dot products, the hit
-// point and the barycentrics are v_pk_fma/v_pk_mul/v_pk_add, only rcp and the min3/compare/select
-// decision run once per ray.  Same decision logic as closest_hit_n; |d.n| >= 1e-6 is tested as
-// (d.n)^2 - 1e-12 > 0 because packed instructions have no |x| operand modifier.
-typedef float f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2 splat(float s) { return (f2)(s); }
-__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-
-__device__ __forceinline__ void closest_hit2(const float4* __restrict__ tri_rows, int n_tris,
-                                             const DevSphere* __restrict__ spheres, int n_spheres, const V3 (&o)[2],
-                                             const V3 (&d)[2], bool lights, const bool (&back_cull)[2], Hit (&out)[2]) {
-    const uint32_t INF_BITS = 0x7f800000u;
-    const f2 ox = {o[0].x, o[1].x}, oy = {o[0].y, o[1].y}, oz = {o[0].z, o[1].z};
-    const f2 dx = {d[0].x, d[1].x}, dy = {d[0].y, d[1].y}, dz = {d[0].z, d[1].z};
-    const f2 cull = {back_cull[0] ? 0.0f : __builtin_inff(), back_cull[1] ? 0.0f : __builtin_inff()};
+    const f2 ox = {o0.x, o1.x}, oy = {o0.y, o1.y}, oz = {o0.z, o1.z};
+    const f2 dx = {d0.x, d1.x}, dy = {d0.y, d1.y}, dz = {d0.z, d1.z};
+    const f2 cull = {back_cull0 ? 0.0f : __builtin_inff(), back_cull1 ? 0.0f : __builtin_inff()};
     uint32_t best0 = INF_BITS, best1 = INF_BITS;
     int prim0 = -1, prim1 = -1, back0 = 0, back1 = 0;
-    for (int i = 0; i < n_tris; ++i) {
-        const float4 rn = tri_rows[3 * i + 0];
-        const float4 ra = tri_rows[3 * i + 1];
-        const float4 rb = tri_rows[3 * i + 2];
+    for (int g = 0; g < n_planes; ++g) {
+        const float4 rn = planes[g];
+        const int k0 = plane_first[g], k1 = plane_first[g + 1];
         const f2 dn = fma2(splat(rn.z), dz, fma2(splat(rn.y), dy, splat(rn.x) * dx));
         const f2 q = fma2(splat(rn.z), oz, fma2(splat(rn.y), oy, fma2(splat(rn.x), ox, splat(-rn.w))));  // n.o - n.v0
         const f2 inv = {__builtin_amdgcn_rcpf(dn.x), __builtin_amdgcn_rcpf(dn.y)};
         const f2 t = -q * inv;
-        const f2 px = fma2(dx, t, ox), py = fma2(dy, t, oy), pz = fma2(dz, t, oz);
-        const f2 u = fma2(splat(ra.z), pz, fma2(splat(ra.y), py, fma2(splat(ra.x), px, splat(ra.w))));
-        const f2 v = fma2(splat(rb.z), pz, fma2(splat(rb.y), py, fma2(splat(rb.x), px, splat(rb.w))));
-        const f2 w = (splat(1.0f) - u) - v;
         const f2 e = fma2(dn, dn, splat(-1e-12f));
         const f2 c = cull - dn;
-        const float m0 = fminf(fminf(fminf(u.x, v.x), w.x), fminf(e.x, c.x));
-        const float m1 = fminf(fminf(fminf(u.y, v.y), w.y), fminf(e.y, c.y));
-        const uint32_t tt0 = (m0 > 0.0f) ? __float_as_uint(t.x) : INF_BITS;
-        const uint32_t tt1 = (m1 > 0.0f) ? __float_as_uint(t.y) : INF_BITS;
+        const uint32_t tp0 = (fminf(e.x, c.x) > 0.0f) ? __float_as_uint(t.x) : INF_BITS;
+        const uint32_t tp1 = (fminf(e.y, c.y) > 0.0f) ? __float_as_uint(t.y) : INF_BITS;
+        if (!__any((tp0 < best0) | (tp1 < best1))) continue;  // wave-uniform
+        const f2 px = fma2(dx, t, ox), py = fma2(dy, t, oy), pz = fma2(dz, t, oz);
+        int hit0 = -1, hit1 = -1;
+        for (int k = k1 - 1; k >= k0; --k) {
+            const float4 ra = tri_uv[2 * k + 0];
+            const float4 rb = tri_uv[2 * k + 1];
+            const f2 u = fma2(splat(ra.z), pz, fma2(splat(ra.y), py, fma2(splat(ra.x), px, splat(ra.w))));
+            const f2 v = fma2(splat(rb.z), pz, fma2(splat(rb.y), py, fma2(splat(rb.x), px, splat(rb.w))));
+            const f2 w = (splat(1.0f) - u) - v;
+            hit0 = (fminf(fminf(u.x, v.x), w.x) > 0.0f) ? k : hit0;
+            hit1 = (fminf(fminf(u.y, v.y), w.y) > 0.0f) ? k : hit1;
+        }
+        const uint32_t tt0 = (hit0 >= 0) ? tp0 : INF_BITS;
+        const uint32_t tt1 = (hit1 >= 0) ? tp1 : INF_BITS;
         const bool cl0 = tt0 < best0, cl1 = tt1 < best1;
-        best0 = cl0 ? tt0 : best0; prim0 = cl0 ? i : prim0;
-        best1 = cl1 ? tt1 : best1; prim1 = cl1 ? i : prim1;
+        best0 = cl0 ? tt0 : best0; prim0 = cl0 ? hit0 : prim0;
+        best1 = cl1 ? tt1 : best1; prim1 = cl1 ? hit1 : prim1;
     }
+    // Spheres and lights.  getSphereCollision (T3DR.py:572-598), Ray.getTSphere (T3DE.py:145-163).
     for (int s = 0; s < n_spheres; ++s) {
         const DevSphere sp = spheres[s];
         if (sp.is_light && !lights) continue;  // wave-uniform
@@ -293,7 +254,7 @@ __device__ __forceinline__ void closest_hit2(const float4* __restrict__ tri_rows
         const f2 t1 = -b - root, t2 = -b + root;
         {
             const bool front = t1.x > 0.0f;
-            const bool inside = (!front) & (t2.x > 0.0f) & (!back_cull[0]) & (sp.is_light == 0);
+            const bool inside = (!front) & (t2.x > 0.0f) & (!back_cull0) & (sp.is_light == 0);
             const bool ok = (disc.x >= 0.0f) & (front | inside);
             const uint32_t tt = ok ? __float_as_uint(front ? t1.x : t2.x) : INF_BITS;
             const bool closer = tt < best0;
@@ -301,37 +262,15 @@ __device__ __forceinline__ void closest_hit2(const float4* __restrict__ tri_rows
         }
         {
             const bool front = t1.y > 0.0f;
-            const bool inside = (!front) & (t2.y > 0.0f) & (!back_cull[1]) & (sp.is_light == 0);
+            const bool inside = (!front) & (t2.y > 0.0f) & (!back_cull1) & (sp.is_light == 0);
             const bool ok = (disc.y >= 0.0f) & (front | inside);
             const uint32_t tt = ok ? __float_as_uint(front ? t1.y : t2.y) : INF_BITS;
             const bool closer = tt < best1;
             best1 = closer ? tt : best1; prim1 = closer ? n_tris + s : prim1; back1 = closer ? (front ? 0 : 1) : back1;
         }
     }
-    out[0].t = __uint_as_float(best0); out[0].prim = prim0; out[0].back = back0;
-    out[1].t = __uint_as_float(best1); out[1].prim = prim1; out[1].back = back1;
-}
-
-__device__ __forceinline__ Hit closest_hit(const float4* __restrict__ tri_rows, int n_tris,
-                                           const DevSphere* __restrict__ spheres, int n_spheres, V3 o, V3 d,
-                                           bool lights, bool back_cull) {
-    const V3 oo[1] = {o}, dd[1] = {d};
-    const bool bc[1] = {back_cull};
-    Hit h[1];
-    closest_hit_n<1>(tri_rows, n_tris, spheres, n_spheres, oo, dd, lights, bc, h);
-    return h[0];
-}
-
-// wave64 compaction: index in [*counter .. ) for every lane with pred, one atomic per wave
-__device__ __forceinline__ int wave_append(int* counter, bool pred) {
-    unsigned long long m = __ballot(pred);
-    if (m == 0ull) return -1;
-    int lane = (int)__lane_id();
-    int leader = __ffsll((long long)m) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(counter, __popcll(m));
-    base = __shfl(base, leader);
-    return base + __popcll(m & ((1ull << lane) - 1ull));
+    out0.t = __uint_as_float(best0); out0.prim = prim0; out0.back = back0;
+    out1.t = __uint_as_float(best1); out1.prim = prim1; out1.back = back1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -359,315 +298,349 @@ __device__ __forceinline__ void camera_ray(const DevCamera& cam, const RenderPar
     d = normalize(v);
 }
 
-// Direct-light terms of two (node, light) pairs per lane: getDirectLight for one light each
-// (T3DR.py:839-894) with getVisibility (T3DR.py:762-778).  The shadow rays see both faces and Light objects.
-__device__ __forceinline__ void shadow_items2(const DevScene& sc, const float4* __restrict__ tri_rows,
-                                              const DevSphere* __restrict__ spheres, const V3 (&P)[2], const V3 (&N)[2],
-                                              const float (&rough)[2], const int (&l)[2], float (&I)[2]) {
+// Direct-light term of a (node, light) pair given the closest hit of its shadow ray: getDirectLight for
+// one light (T3DR.py:839-894) with getVisibility (T3DR.py:762-778).
+struct ShadowRay {
+    V3 P, N, Ld, start;
+    float rough, dist2, strength;
+};
+__device__ __forceinline__ ShadowRay shadow_ray(const DevScene& sc, float4 ra, float4 rb, int l) {
+    ShadowRay s;
+    s.P = mk(ra.x, ra.y, ra.z); s.N = mk(rb.x, rb.y, rb.z); s.rough = ra.w;
+    const DevLight lt = sc.lights[l];
+    const V3 to = mk(lt.x - s.P.x, lt.y - s.P.y, lt.z - s.P.z);
+    s.dist2 = dot(to, to);
+    s.Ld = to * __builtin_amdgcn_rsqf(s.dist2);
+    s.start = madd(s.P, s.Ld, 0.2f);  // T3DR.py:840
+    s.strength = lt.strength;
+    return s;
+}
+__device__ __forceinline__ float shadow_intensity(const DevScene& sc, const DevSphere* __restrict__ spheres, const ShadowRay& s,
+                                                  const Hit& h) {
     const V3 cam = mk(sc.cam.pos[0], sc.cam.pos[1], sc.cam.pos[2]);
-    V3 Ld[2], start[2];
-    float dist2[2], strength[2];
-    const bool cull[2] = {false, false};
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const DevLight lt = sc.lights[l[r]];
-        const V3 to = mk(lt.x - P[r].x, lt.y - P[r].y, lt.z - P[r].z);
-        dist2[r] = dot(to, to);
-        Ld[r] = to * __builtin_amdgcn_rsqf(dist2[r]);
-        start[r] = madd(P[r], Ld[r], 0.2f);
-        strength[r] = lt.strength;
+    float vis = 1.0f;
+    if (h.prim >= 0) {
+        if (h.prim < sc.n_tris) {
+            DevShader bs = sc.shaders[sc.tri_meta[h.prim].z];
+            if (!(bs.emis > 0.0f)) vis = 1.0f - bs.refl;
+        } else {
+            DevSphere sp = spheres[h.prim - sc.n_tris];
+            if (!sp.is_light) vis = 1.0f - sc.shaders[sp.shader].refl;
+        }
     }
-    Hit h[2];
-    closest_hit2(tri_rows, sc.n_tris, spheres, sc.n_spheres, start, Ld, true, cull, h);
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        float vis = 1.0f;
-        if (h[r].prim >= 0) {
-            if (h[r].prim < sc.n_tris) {
-                DevShader bs = sc.shaders[sc.tri_meta[h[r].prim].z];
-                if (!(bs.emis > 0.0f)) vis = 1.0f - bs.refl;
-            } else {
-                DevSphere sp = spheres[h[r].prim - sc.n_tris];
-                if (!sp.is_light) vis = 1.0f - sc.shaders[sp.shader].refl;
+    const float ldn = dot(s.Ld, s.N);
+    const float diffuse = fmaxf(0.0f, ldn);
+    const V3 R = madd(s.Ld * -1.0f, s.N, 2.0f * ldn);
+    const float spec = (dot(normalize(R), normalize(cam - s.P)) < 0.96f) ? 0.0f : 1.0f;
+    return (diffuse * s.rough + spec * (1.0f - s.rough)) * s.strength * vis * attenuation(s.dist2);
+}
+
+// What a wave needs to know about itself
+struct WaveCtx {
+    int lane, wid, shard, shard_cap, level, L;
+    size_t node_base;
+    unsigned long long lt_mask;
+};
+
+// One ray of a trace round
+struct RayIn {
+    V3 o, d, pstart;
+    float ior;
+    int inside_obj, parent, side;
+    uint32_t ps, heap;
+    int px, py, smp;
+    int i;  // index in the level's queue (level 0: sample index)
+    bool active;
+};
+
+// Everything that follows the closest hit of ONE ray per lane (wave-collective: ballots and atomics):
+// classification, emitter / miss leaves, bounce and transmit rays, node record, queue appends, ring entry.
+template <bool LEVEL0>
+__device__ __forceinline__ void process_ray(const DevScene& sc, const DevSphere* __restrict__ spheres, const RenderParams& rp,
+                                            const WaveCtx& wc, const RayIn& in, const Hit& h, RayRec* __restrict__ rays_out,
+                                            const NodePool& pool, Counters* cnt, const TraceOut& out, float4* ring_a,
+                                            float4* ring_b, int& ring_nodes) {
+    const V3 o = in.o, d = in.d;
+    const bool hit = in.active && h.prim >= 0;
+    // ---- classify ---------------------------------------------------------------------
+    V3 P = madd(o, d, h.t);
+    V3 N = mk(0, 0, 1);      // unit normal as used by bounce / transmit / direct light
+    V3 Nraw = mk(0, 0, 1);   // normal as the reference stores it (debug records)
+    int obj = -1, face = -1, shader = 0, dirflag = 0;
+    bool emitter = false;
+    V3 emit = mk(0, 0, 0);
+    float strength = 1.0f;
+    if (hit) {
+        if (h.prim < sc.n_tris) {
+            int4 meta = sc.tri_meta[h.prim];
+            float4 rn = sc.tri_n[h.prim];
+            obj = meta.x; face = meta.y; shader = meta.z;
+            Nraw = mk(rn.x, rn.y, rn.z);
+            N = normalize(Nraw);
+            dirflag = (dot(Nraw, d) < 0.0f) ? 0 : 1;
+            DevShader sh = sc.shaders[shader];
+            emitter = sh.emis > 0.0f;
+            strength = sh.emis;
+        } else {
+            DevSphere sp = spheres[h.prim - sc.n_tris];
+            obj = sp.obj; shader = sp.shader; dirflag = h.back;
+            N = normalize(mk(P.x - sp.cx, P.y - sp.cy, P.z - sp.cz));
+            Nraw = N;
+            emitter = sp.is_light != 0;
+            strength = sp.strength;
+        }
+        if (emitter) {
+            // computeColor for lights / emissive faces (T3DR.py:1014-1041): distance to the camera
+            DevShader sh = sc.shaders[shader];
+            V3 pc = mk(P.x - sc.cam.pos[0], P.y - sc.cam.pos[1], P.z - sc.cam.pos[2]);
+            float att = attenuation(dot(pc, pc));
+            emit = mk(fminf(sh.r * strength * att, 255.0f), fminf(sh.g * strength * att, 255.0f),
+                      fminf(sh.b * strength * att, 255.0f));
+        }
+    }
+    if (LEVEL0 && in.active) {
+        if (in.smp == 0 || rp.single) {
+            int pix = rp.single ? 0 : in.i / rp.samples;
+            if (out.primary) { out.primary[2 * pix] = obj; out.primary[2 * pix + 1] = face; }
+            if (out.primary_t) out.primary_t[pix] = hit ? h.t : __builtin_nanf("");
+        }
+    }
+    // attenuation of this node's colour on its way into the parent: |P - parent.ray.start|
+    V3 pp = P - in.pstart;
+    const float att_parent = LEVEL0 ? 1.0f : attenuation(dot(pp, pp));
+
+    // ---- debug record (single-pixel mode) ----------------------------------------------
+    int dbg_idx = -1;
+    if (rp.want_debug && hit) {
+        dbg_idx = atomicAdd(&cnt->n_dbg, 1);
+        if (dbg_idx < out.dbg_cap) {
+            t3d_node& nd = out.dbg[dbg_idx];
+            nd.heap = (int)in.heap; nd.obj = obj; nd.face = face; nd.direction = dirflag; nd.t = h.t;
+            nd.point[0] = P.x; nd.point[1] = P.y; nd.point[2] = P.z;
+            nd.normal[0] = Nraw.x; nd.normal[1] = Nraw.y; nd.normal[2] = Nraw.z;
+            nd.ray_start[0] = o.x; nd.ray_start[1] = o.y; nd.ray_start[2] = o.z;
+            nd.ray_dir[0] = d.x; nd.ray_dir[1] = d.y; nd.ray_dir[2] = d.z;
+            nd.ray_ior = in.ior; nd.ray_obj = in.inside_obj;
+            nd.color[0] = emit.x; nd.color[1] = emit.y; nd.color[2] = emit.z;
+        }
+    }
+
+    // ---- leaves -------------------------------------------------------------------------
+    if (in.active && (!hit || emitter)) {
+        if (LEVEL0) {
+            V3 c = hit ? emit : mk(rp.ambient[0], rp.ambient[1], rp.ambient[2]);  // T3DR.py:1006-1007
+            out.sample_color[in.i] = make_float4(c.x, c.y, c.z, 0.0f);
+        } else if (hit) {
+            float4* slot = in.side ? pool.d : pool.c;
+            float4 cur = slot[in.parent];
+            cur.x = emit.x * att_parent; cur.y = emit.y * att_parent; cur.z = emit.z * att_parent;
+            slot[in.parent] = cur;
+        }
+    }
+
+    // ---- shaded node and its children (T3DR.py:979-995) --------------------------------------
+    const bool shaded = hit && !emitter;
+    bool want_t = false, want_b = false;
+    V3 tdir = mk(0, 0, 1), bdir = mk(0, 0, 1), tstart = P, bstart = P;
+    float t_ior = 1.0f, rough = 1.0f;
+    int t_obj = -1;
+    if (shaded) {
+        DevShader sh = sc.shaders[shader];
+        const float refl = sh.refl;
+        rough = sh.rough;
+        if (wc.level < rp.bounces) {
+            if (refl != 1.0f) {
+                // transmit (T3DR.py:904-956)
+                V3 Nn = N;
+                float n2 = sc.obj_ior[obj];
+                int nobj = obj;
+                if (obj == in.inside_obj) { Nn = N * -1.0f; n2 = 1.0f; nobj = -1; }
+                float cosI = -dot(d, Nn);
+                float ratio = in.ior / n2;
+                float sin2T = ratio * ratio * (1.0f - cosI * cosI);
+                if (!(sin2T > 1.0f)) {
+                    float cosT = __builtin_sqrtf(1.0f - sin2T);
+                    V3 spec = madd(d * ratio, Nn, ratio * cosI - cosT);
+                    V3 diff = normalize(keyed_cube(rp.seed, (uint32_t)in.px, (uint32_t)in.py, (uint32_t)in.smp, 2u * in.heap + 1u));
+                    if (dot(diff, Nn) > 0.0f) diff = diff * -1.0f;
+                    V3 dir = madd(spec * (1.0f - rough), diff, rough);
+                    tstart = madd(P, dir, 0.1f);
+                    tdir = normalize(dir);
+                    t_ior = n2; t_obj = nobj;
+                    want_t = true;
+                }
+            }
+            if (refl != 0.0f) {
+                // bounce (T3DR.py:733-759)
+                V3 diff = normalize(keyed_cube(rp.seed, (uint32_t)in.px, (uint32_t)in.py, (uint32_t)in.smp, 2u * in.heap));
+                if (dot(diff, N) < 0.0f) diff = diff * -1.0f;
+                V3 spec = madd(d, N, -2.0f * dot(d, N));
+                V3 dir = madd(spec * (1.0f - rough), diff, rough);
+                bstart = madd(P, dir, 0.1f);
+                bdir = normalize(dir);
+                want_b = true;
             }
         }
-        const float ldn = dot(Ld[r], N[r]);
-        const float diffuse = fmaxf(0.0f, ldn);
-        const V3 R = madd(Ld[r] * -1.0f, N[r], 2.0f * ldn);
-        const float spec = (dot(normalize(R), normalize(cam - P[r])) < 0.96f) ? 0.0f : 1.0f;
-        I[r] = (diffuse * rough[r] + spec * (1.0f - rough[r])) * strength[r] * vis * attenuation(dist2[r]);
+    }
+
+    // ---- append: node slot and child-ray slots (wave64 ballot + prefix popcount) --------------------
+    const unsigned long long m_n = __ballot(shaded), m_t = __ballot(want_t), m_b = __ballot(want_b);
+    const int c_n = __popcll(m_n), c_t = __popcll(m_t), c_b = __popcll(m_b);
+    int base_n = 0, base_r = 0;
+    if (wc.lane == 0) {   // both atomics are issued before either result is needed
+        if (c_n) base_n = atomicAdd(&cnt->n_nodes[wc.level][wc.shard].v, c_n);
+        if (c_t + c_b) base_r = atomicAdd(&cnt->n_rays[wc.level + 1][wc.shard].v, c_t + c_b);
+    }
+    base_n = __shfl(base_n, 0);
+    base_r = __shfl(base_r, 0);
+    const int nrank = __popcll(m_n & wc.lt_mask);
+    const int nloc = base_n + nrank;                                  // index within the shard
+    const int tloc = base_r + __popcll(m_t & wc.lt_mask);
+    const int bloc = base_r + c_t + __popcll(m_b & wc.lt_mask);
+    const int node = wc.shard * wc.shard_cap + nloc;                  // index within the level
+    const bool stored = shaded && nloc < wc.shard_cap;
+    if (shaded && !stored) cnt->overflow = 1;
+    if (stored) {
+        const float k = 2.0f / 255.0f;  // absent children count as ambient * 2/255 (T3DR.py:1054-1055)
+        const size_t g = wc.node_base + (size_t)node;
+        pool.a[g] = make_float4(P.x, P.y, P.z, att_parent);
+        pool.b[g] = make_float4(N.x, N.y, N.z, __int_as_float(shader | (in.side << 30)));
+        pool.c[g] = make_float4(rp.ambient[0] * k, rp.ambient[1] * k, rp.ambient[2] * k, __int_as_float(in.parent));
+        pool.d[g] = make_float4(rp.ambient[0] * k, rp.ambient[1] * k, rp.ambient[2] * k, 0.0f);
+        if (rp.want_debug) pool.dbg[g] = dbg_idx;
+    }
+    if (want_t && stored) {
+        if (tloc < wc.shard_cap) {
+            RayRec r;
+            r.o = make_float4(tstart.x, tstart.y, tstart.z, t_ior);
+            r.d = make_float4(tdir.x, tdir.y, tdir.z, __int_as_float(t_obj));
+            r.p = make_float4(o.x, o.y, o.z, __int_as_float((int)(wc.node_base + node)));
+            r.k = make_uint4(in.ps, 2u * in.heap + 1u, 1u, (uint32_t)dbg_idx);
+            rays_out[wc.shard * wc.shard_cap + tloc] = r;
+        } else cnt->overflow = 1;
+    }
+    if (want_b && stored) {
+        if (bloc < wc.shard_cap) {
+            RayRec r;
+            r.o = make_float4(bstart.x, bstart.y, bstart.z, in.ior);
+            r.d = make_float4(bdir.x, bdir.y, bdir.z, __int_as_float(in.inside_obj));
+            r.p = make_float4(o.x, o.y, o.z, __int_as_float((int)(wc.node_base + node)));
+            r.k = make_uint4(in.ps, 2u * in.heap, 0u, (uint32_t)dbg_idx);
+            rays_out[wc.shard * wc.shard_cap + bloc] = r;
+        } else cnt->overflow = 1;
+    }
+    // shaded nodes enter the wave's ring in lane order
+    if (shaded && wc.L > 0) {
+        const int slot = (ring_nodes + nrank) % T3D_RING;
+        ring_a[slot] = make_float4(P.x, P.y, P.z, rough);
+        ring_b[slot] = make_float4(N.x, N.y, N.z, __int_as_float(stored ? node : 0));
+    }
+    ring_nodes += c_n;
+}
+
+template <bool LEVEL0>
+__device__ __forceinline__ void load_ray(const DevScene& sc, const RenderParams& rp, const RayRec* __restrict__ rays_in,
+                                         int idx, int n_in, int queue_base, RayIn& in) {
+    in.active = idx < n_in;
+    in.i = LEVEL0 ? idx : queue_base + idx;
+    in.o = mk(0, 0, 0); in.d = mk(0, 0, 1); in.pstart = mk(0, 0, 0);
+    in.ior = 1.0f; in.inside_obj = -1; in.parent = -1; in.side = 0;
+    in.ps = 0; in.heap = 1; in.px = 0; in.py = 0; in.smp = 0;
+    if (in.active) {
+        if (LEVEL0) {
+            in.ps = (uint32_t)in.i;
+            in.parent = in.i;
+        } else {
+            RayRec r = rays_in[in.i];
+            in.o = mk(r.o.x, r.o.y, r.o.z); in.ior = r.o.w;
+            in.d = mk(r.d.x, r.d.y, r.d.z); in.inside_obj = __float_as_int(r.d.w);
+            in.pstart = mk(r.p.x, r.p.y, r.p.z); in.parent = __float_as_int(r.p.w);
+            in.ps = r.k.x; in.heap = r.k.y; in.side = (int)r.k.z;
+        }
+        int pix = (int)in.ps / rp.samples;
+        in.smp = (int)in.ps - pix * rp.samples;
+        int ly = pix / rp.width;
+        in.px = pix - ly * rp.width;
+        in.py = rp.row0 + ly * rp.row_stride;
+        if (rp.single) { in.px = rp.px0; in.py = rp.py0; in.smp = rp.sample0; }
+        if (LEVEL0) camera_ray(sc.cam, rp, in.px, in.py, in.o, in.d);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // k_level: everything one tree level needs, one launch.
 //
-// Every WAVE is an autonomous scheduler over two kinds of closest-hit work, one query per lane per round:
-//   trace round   the next 64 rays of the level's queue: closest hit, classification, child rays,
+// Every WAVE is an autonomous scheduler over two kinds of closest-hit work, two queries per lane per round:
+//   trace round   the next 128 rays of the level's queue: closest hit, classification, child rays,
 //                 node records; the shaded nodes also enter the wave's ring buffer in LDS
-//   shadow round  64 (node, light) pairs from the ring: shadow-ray closest hit -> li[node][light]
-// A shadow round runs whenever 64 pairs are pending (or the queue is exhausted), so lanes stay busy even
+//   shadow round  128 (node, light) pairs from the ring: shadow-ray closest hit -> li[node][light]
+// A shadow round runs whenever 128 pairs are pending (or the queue is exhausted), so lanes stay busy even
 // though only part of the rays produce shaded nodes, and node data for shading never leaves LDS.
 // There is no block-level synchronisation at all.
 //
 // Queues are sharded T3D_SHARDS ways: wave w appends to shard w % T3D_SHARDS (own counter in its own
 // 64-byte line, own slice of the arrays) with wave64 ballot + prefix-popcount compaction and ONE atomic
-// per counter per round.  Same-address device-scope atomics retire at roughly one per 7 ns, so a single
-// counter per level would serialise the whole kernel; 64 counters do not.
+// per counter per 64 rays.
 // ------------------------------------------------------------------------------------------------
-#define T3D_RING 192 /* nodes per wave; pending pairs < 128 before a trace round, which adds at most 64 nodes */
 template <bool LEVEL0>
-__global__ __launch_bounds__(T3D_TRACE_BLOCK) void k_level(DevScene sc, const float4* __restrict__ tri_rows,
-                                                     const DevSphere* __restrict__ spheres, RenderParams rp, int level,
+__global__ __launch_bounds__(T3D_BLOCK) void k_level(DevScene sc, GEO_PARAMS, RenderParams rp, int level,
                                                      const RayRec* __restrict__ rays_in, RayRec* __restrict__ rays_out,
                                                      NodePool pool, Counters* cnt, TraceOut out) {
-    __shared__ float4 ring_a[T3D_TRACE_BLOCK / 64][T3D_RING];  // P.xyz, roughness
-    __shared__ float4 ring_b[T3D_TRACE_BLOCK / 64][T3D_RING];  // unit normal, int bits: node index within the level
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const int gw = blockIdx.x * (T3D_TRACE_BLOCK / 64) + wid;      // global wave id
-    const int nw = gridDim.x * (T3D_TRACE_BLOCK / 64);             // multiple of T3D_SHARDS (host guarantees)
-    const int shard = gw % T3D_SHARDS;
-    const int shard_cap = rp.cap / T3D_SHARDS;
-    const size_t node_base = (size_t)level * rp.cap;
-    const int L = sc.n_lights;
+    __shared__ float4 ring_a_all[T3D_WAVES][T3D_RING];  // P.xyz, roughness
+    __shared__ float4 ring_b_all[T3D_WAVES][T3D_RING];  // unit normal, int bits: node index within the level
+    WaveCtx wc;
+    wc.lane = threadIdx.x & 63; wc.wid = threadIdx.x >> 6;
+    wc.lt_mask = (1ull << wc.lane) - 1ull;
+    const int gw = blockIdx.x * T3D_WAVES + wc.wid;  // global wave id
+    const int nw = gridDim.x * T3D_WAVES;            // multiple of T3D_SHARDS (host guarantees)
+    wc.shard = gw % T3D_SHARDS;
+    wc.shard_cap = rp.cap / T3D_SHARDS;
+    wc.level = level;
+    wc.node_base = (size_t)level * rp.cap;
+    wc.L = sc.n_lights;
+    float4* ring_a = ring_a_all[wc.wid];
+    float4* ring_b = ring_b_all[wc.wid];
+    const int L = wc.L;
     // input: level 0 is the dense list of primary samples; deeper levels read this wave's shard of the queue
-    const int n_in = LEVEL0 ? rp.n0 : min(cnt->n_rays[level][shard].v, shard_cap);
-    int chunk = LEVEL0 ? gw : gw / T3D_SHARDS;                     // in units of 64 rays
+    const int n_in = LEVEL0 ? rp.n0 : min(cnt->n_rays[level][wc.shard].v, wc.shard_cap);
+    const int queue_base = wc.shard * wc.shard_cap;
+    int chunk = LEVEL0 ? gw : gw / T3D_SHARDS;  // in units of 128 rays
     const int chunk_step = LEVEL0 ? nw : nw / T3D_SHARDS;
     int ring_nodes = 0;  // nodes appended to the ring so far      (wave-uniform)
     int items_done = 0;  // (node, light) pairs already traced     (wave-uniform)
     for (;;) {
         const int pending = ring_nodes * L - items_done;
-        const bool more = (long long)chunk * 64 < n_in;
+        const bool more = (long long)chunk * 128 < n_in;
         if (pending >= 128 || (!more && pending > 0)) {
-            // ---------------- shadow round: two pairs per lane (items lane and lane + 64) ----------------
-            V3 P[2], N[2];
-            float rough[2], I[2];
-            int l[2], gnode[2];
-            bool run[2];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int item = items_done + lane + 64 * r;
-                run[r] = item < ring_nodes * L;
-                const int it = run[r] ? item : items_done;
-                const int nd = it / L;
-                l[r] = it - nd * L;
-                const float4 ra = ring_a[wid][nd % T3D_RING], rb = ring_b[wid][nd % T3D_RING];
-                P[r] = mk(ra.x, ra.y, ra.z); N[r] = mk(rb.x, rb.y, rb.z); rough[r] = ra.w; gnode[r] = __float_as_int(rb.w);
-            }
-            shadow_items2(sc, tri_rows, spheres, P, N, rough, l, I);
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-                if (run[r]) pool.li[(node_base + (size_t)gnode[r]) * L + l[r]] = I[r];
+            // ---------------- shadow round: pairs items_done + lane and items_done + 64 + lane ----------------
+            const int item0 = items_done + wc.lane, item1 = item0 + 64;
+            const bool run0 = item0 < ring_nodes * L, run1 = item1 < ring_nodes * L;
+            const int it0 = run0 ? item0 : items_done, it1 = run1 ? item1 : items_done;
+            const int nd0 = it0 / L, nd1 = it1 / L;
+            const int l0 = it0 - nd0 * L, l1 = it1 - nd1 * L;
+            const float4 rb0 = ring_b[nd0 % T3D_RING], rb1 = ring_b[nd1 % T3D_RING];
+            const ShadowRay s0 = shadow_ray(sc, ring_a[nd0 % T3D_RING], rb0, l0);
+            const ShadowRay s1 = shadow_ray(sc, ring_a[nd1 % T3D_RING], rb1, l1);
+            Hit h0, h1;
+            closest_hit2(GEO_ARGS, sc.n_planes, sc.n_tris, sc.n_spheres, s0.start, s0.Ld, s1.start, s1.Ld, true, false, false, h0, h1);
+            const float I0 = shadow_intensity(sc, spheres, s0, h0), I1 = shadow_intensity(sc, spheres, s1, h1);
+            if (run0) pool.li[(wc.node_base + (size_t)__float_as_int(rb0.w)) * L + l0] = I0;
+            if (run1) pool.li[(wc.node_base + (size_t)__float_as_int(rb1.w)) * L + l1] = I1;
             items_done += pending < 128 ? pending : 128;
         } else if (more) {
-            // ---------------- trace round ----------------
-            const int idx = chunk * 64 + lane;
-            const bool active = idx < n_in;
-            const int i = LEVEL0 ? idx : shard * shard_cap + idx;
-            V3 o = mk(0, 0, 0), d = mk(0, 0, 1), pstart = mk(0, 0, 0);
-            float ior = 1.0f;
-            int inside_obj = -1, parent = -1, side = 0;
-            uint32_t ps = 0, heap = 1;
-            int px = 0, py = 0, smp = 0;
-            if (active) {
-                if (LEVEL0) {
-                    ps = (uint32_t)i;
-                    parent = i;
-                } else {
-                    RayRec r = rays_in[i];
-                    o = mk(r.o.x, r.o.y, r.o.z); ior = r.o.w;
-                    d = mk(r.d.x, r.d.y, r.d.z); inside_obj = __float_as_int(r.d.w);
-                    pstart = mk(r.p.x, r.p.y, r.p.z); parent = __float_as_int(r.p.w);
-                    ps = r.k.x; heap = r.k.y; side = (int)r.k.z;
-                }
-                int pix = (int)ps / rp.samples;
-                smp = (int)ps - pix * rp.samples;
-                int ly = pix / rp.width;
-                px = pix - ly * rp.width;
-                py = rp.row0 + ly * rp.row_stride;
-                if (rp.single) { px = rp.px0; py = rp.py0; smp = rp.sample0; }
-                if (LEVEL0) camera_ray(sc.cam, rp, px, py, o, d);
-            }
+            // ---------------- trace round: rays chunk*128 + lane and chunk*128 + 64 + lane ----------------
+            RayIn in0, in1;
+            load_ray<LEVEL0>(sc, rp, rays_in, chunk * 128 + wc.lane, n_in, queue_base, in0);
+            load_ray<LEVEL0>(sc, rp, rays_in, chunk * 128 + 64 + wc.lane, n_in, queue_base, in1);
             const bool lights = LEVEL0 ? (rp.lights != 0) : true;
-            const bool back_cull = (ior == 1.0f);  // T3DR.py:961
-            Hit h = closest_hit(tri_rows, sc.n_tris, spheres, sc.n_spheres, o, d, lights, back_cull);
-            const bool hit = active && h.prim >= 0;
-
-            // ---- classify ---------------------------------------------------------------------
-            V3 P = madd(o, d, h.t);
-            V3 N = mk(0, 0, 1);      // unit normal as used by bounce / transmit / direct light
-            V3 Nraw = mk(0, 0, 1);   // normal as the reference stores it (debug records)
-            int obj = -1, face = -1, shader = -1, dirflag = 0;
-            bool emitter = false;
-            V3 emit = mk(0, 0, 0);
-            float strength = 1.0f;
-            if (hit) {
-                if (h.prim < sc.n_tris) {
-                    int4 meta = sc.tri_meta[h.prim];
-                    float4 rn = tri_rows[3 * h.prim];
-                    obj = meta.x; face = meta.y; shader = meta.z;
-                    Nraw = mk(rn.x, rn.y, rn.z);
-                    N = normalize(Nraw);
-                    dirflag = (dot(Nraw, d) < 0.0f) ? 0 : 1;
-                    DevShader sh = sc.shaders[shader];
-                    emitter = sh.emis > 0.0f;
-                    strength = sh.emis;
-                } else {
-                    DevSphere sp = spheres[h.prim - sc.n_tris];
-                    obj = sp.obj; shader = sp.shader; dirflag = h.back;
-                    N = normalize(mk(P.x - sp.cx, P.y - sp.cy, P.z - sp.cz));
-                    Nraw = N;
-                    emitter = sp.is_light != 0;
-                    strength = sp.strength;
-                }
-                if (emitter) {
-                    // computeColor for lights / emissive faces (T3DR.py:1014-1041): distance to the camera
-                    DevShader sh = sc.shaders[shader];
-                    V3 pc = mk(P.x - sc.cam.pos[0], P.y - sc.cam.pos[1], P.z - sc.cam.pos[2]);
-                    float att = attenuation(dot(pc, pc));
-                    emit = mk(fminf(sh.r * strength * att, 255.0f), fminf(sh.g * strength * att, 255.0f),
-                              fminf(sh.b * strength * att, 255.0f));
-                }
-            }
-            if (LEVEL0 && active) {
-                if (smp == 0 || rp.single) {
-                    int pix = rp.single ? 0 : i / rp.samples;
-                    if (out.primary) { out.primary[2 * pix] = obj; out.primary[2 * pix + 1] = face; }
-                    if (out.primary_t) out.primary_t[pix] = hit ? h.t : __builtin_nanf("");
-                }
-            }
-            // attenuation of this node's colour on its way into the parent: |P - parent.ray.start|
-            V3 pp = P - pstart;
-            const float att_parent = LEVEL0 ? 1.0f : attenuation(dot(pp, pp));
-
-            // ---- debug record (single-pixel mode) ----------------------------------------------
-            int dbg_idx = -1;
-            if (rp.want_debug && hit) {
-                dbg_idx = atomicAdd(&cnt->n_dbg, 1);
-                if (dbg_idx < out.dbg_cap) {
-                    t3d_node& nd = out.dbg[dbg_idx];
-                    nd.heap = (int)heap; nd.obj = obj; nd.face = face; nd.direction = dirflag; nd.t = h.t;
-                    nd.point[0] = P.x; nd.point[1] = P.y; nd.point[2] = P.z;
-                    nd.normal[0] = Nraw.x; nd.normal[1] = Nraw.y; nd.normal[2] = Nraw.z;
-                    nd.ray_start[0] = o.x; nd.ray_start[1] = o.y; nd.ray_start[2] = o.z;
-                    nd.ray_dir[0] = d.x; nd.ray_dir[1] = d.y; nd.ray_dir[2] = d.z;
-                    nd.ray_ior = ior; nd.ray_obj = inside_obj;
-                    nd.color[0] = emit.x; nd.color[1] = emit.y; nd.color[2] = emit.z;
-                }
-            }
-
-            // ---- leaves -------------------------------------------------------------------------
-            if (active && (!hit || emitter)) {
-                if (LEVEL0) {
-                    V3 c = hit ? emit : mk(rp.ambient[0], rp.ambient[1], rp.ambient[2]);  // T3DR.py:1006-1007
-                    out.sample_color[i] = make_float4(c.x, c.y, c.z, 0.0f);
-                } else if (hit) {
-                    float4* slot = side ? pool.d : pool.c;
-                    float4 cur = slot[parent];
-                    cur.x = emit.x * att_parent; cur.y = emit.y * att_parent; cur.z = emit.z * att_parent;
-                    slot[parent] = cur;
-                }
-            }
-
-            // ---- shaded node: what it is and which children it spawns ------------------------------------
-            const bool shaded = hit && !emitter;
-            // ---- children (T3DR.py:979-995) --------------------------------------------------------
-            bool want_t = false, want_b = false;
-            V3 tdir = mk(0, 0, 1), bdir = mk(0, 0, 1), tstart = P, bstart = P;
-            float t_ior = 1.0f;
-            int t_obj = -1;
-            if (shaded && level < rp.bounces) {
-                DevShader sh = sc.shaders[shader];
-                float refl = sh.refl, rough = sh.rough;
-                if (refl != 1.0f) {
-                    // transmit (T3DR.py:904-956)
-                    V3 Nn = N;
-                    float n2 = sc.obj_ior[obj];
-                    int nobj = obj;
-                    if (obj == inside_obj) { Nn = N * -1.0f; n2 = 1.0f; nobj = -1; }
-                    float cosI = -dot(d, Nn);
-                    float ratio = ior / n2;
-                    float sin2T = ratio * ratio * (1.0f - cosI * cosI);
-                    if (!(sin2T > 1.0f)) {
-                        float cosT = __builtin_sqrtf(1.0f - sin2T);
-                        V3 spec = madd(d * ratio, Nn, ratio * cosI - cosT);
-                        V3 diff = normalize(keyed_cube(rp.seed, (uint32_t)px, (uint32_t)py, (uint32_t)smp, 2u * heap + 1u));
-                        if (dot(diff, Nn) > 0.0f) diff = diff * -1.0f;
-                        V3 dir = madd(spec * (1.0f - rough), diff, rough);
-                        tstart = madd(P, dir, 0.1f);
-                        tdir = normalize(dir);
-                        t_ior = n2; t_obj = nobj;
-                        want_t = true;
-                    }
-                }
-                if (refl != 0.0f) {
-                    // bounce (T3DR.py:733-759)
-                    V3 diff = normalize(keyed_cube(rp.seed, (uint32_t)px, (uint32_t)py, (uint32_t)smp, 2u * heap));
-                    if (dot(diff, N) < 0.0f) diff = diff * -1.0f;
-                    V3 spec = madd(d, N, -2.0f * dot(d, N));
-                    V3 dir = madd(spec * (1.0f - rough), diff, rough);
-                    bstart = madd(P, dir, 0.1f);
-                    bdir = normalize(dir);
-                    want_b = true;
-                }
-            }
-            // ---- append: node slot and child-ray slots (wave64 ballot + prefix popcount) --------------------
-            const unsigned long long m_n = __ballot(shaded), m_t = __ballot(want_t), m_b = __ballot(want_b);
-            const int c_n = __popcll(m_n), c_t = __popcll(m_t), c_b = __popcll(m_b);
-            int base_n = 0, base_r = 0;
-            if (lane == 0) {   // both atomics are issued before either result is needed
-                if (c_n) base_n = atomicAdd(&cnt->n_nodes[level][shard].v, c_n);
-                if (c_t + c_b) base_r = atomicAdd(&cnt->n_rays[level + 1][shard].v, c_t + c_b);
-            }
-            base_n = __shfl(base_n, 0);
-            base_r = __shfl(base_r, 0);
-            const int nloc = base_n + __popcll(m_n & lt_mask);          // index within the shard
-            const int tloc = base_r + __popcll(m_t & lt_mask);
-            const int bloc = base_r + c_t + __popcll(m_b & lt_mask);
-            const int node = shard * shard_cap + nloc;                  // index within the level
-            const bool stored = shaded && nloc < shard_cap;
-            if (shaded && !stored) cnt->overflow = 1;
-            if (stored) {
-                const float k = 2.0f / 255.0f;  // absent children count as ambient * 2/255 (T3DR.py:1054-1055)
-                size_t g = node_base + (size_t)node;
-                pool.a[g] = make_float4(P.x, P.y, P.z, att_parent);
-                pool.b[g] = make_float4(N.x, N.y, N.z, __int_as_float(shader | (side << 30)));
-                pool.c[g] = make_float4(rp.ambient[0] * k, rp.ambient[1] * k, rp.ambient[2] * k, __int_as_float(parent));
-                pool.d[g] = make_float4(rp.ambient[0] * k, rp.ambient[1] * k, rp.ambient[2] * k, 0.0f);
-                if (rp.want_debug) pool.dbg[g] = dbg_idx;
-            }
-            if (want_t && stored) {
-                if (tloc < shard_cap) {
-                    RayRec r;
-                    r.o = make_float4(tstart.x, tstart.y, tstart.z, t_ior);
-                    r.d = make_float4(tdir.x, tdir.y, tdir.z, __int_as_float(t_obj));
-                    r.p = make_float4(o.x, o.y, o.z, __int_as_float((int)(node_base + node)));
-                    r.k = make_uint4(ps, 2u * heap + 1u, 1u, (uint32_t)dbg_idx);
-                    rays_out[shard * shard_cap + tloc] = r;
-                } else cnt->overflow = 1;
-            }
-            if (want_b && stored) {
-                if (bloc < shard_cap) {
-                    RayRec r;
-                    r.o = make_float4(bstart.x, bstart.y, bstart.z, ior);
-                    r.d = make_float4(bdir.x, bdir.y, bdir.z, __int_as_float(inside_obj));
-                    r.p = make_float4(o.x, o.y, o.z, __int_as_float((int)(node_base + node)));
-                    r.k = make_uint4(ps, 2u * heap, 0u, (uint32_t)dbg_idx);
-                    rays_out[shard * shard_cap + bloc] = r;
-                } else cnt->overflow = 1;
-            }
-            // shaded nodes enter the wave's ring in lane order
-            if (shaded && L > 0) {
-                const int slot = (ring_nodes + __popcll(m_n & lt_mask)) % T3D_RING;
-                ring_a[wid][slot] = make_float4(P.x, P.y, P.z, sc.shaders[shader].rough);
-                ring_b[wid][slot] = make_float4(N.x, N.y, N.z, __int_as_float(stored ? node : 0));
-            }
-            ring_nodes += c_n;
+            Hit h0, h1;
+            closest_hit2(GEO_ARGS, sc.n_planes, sc.n_tris, sc.n_spheres, in0.o, in0.d, in1.o, in1.d, lights,
+                         in0.ior == 1.0f, in1.ior == 1.0f, h0, h1);  // back faces culled iff ray.ior == 1 (T3DR.py:961)
+            process_ray<LEVEL0>(sc, spheres, rp, wc, in0, h0, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes);
+            process_ray<LEVEL0>(sc, spheres, rp, wc, in1, h1, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes);
             chunk += chunk_step;
-            // the ring is private to this wave; LDS operations of one wave complete in order, the fence
-            // only stops the compiler from moving the next round's reads above these writes
+            // the ring is private to this wave; LDS operations of one wave complete in order, the fences
+            // only stop the compiler from moving the next round's reads above these writes
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -744,25 +717,25 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_finish(RenderParams rp, const flo
     }
 }
 
-// closest hits for arbitrary rays (t3d_closest_hits)
-__global__ __launch_bounds__(T3D_BLOCK) void k_closest(DevScene sc, const float4* __restrict__ tri_rows,
-                                                       const DevSphere* __restrict__ spheres, int n,
-                                                       const float* __restrict__ origins, const float* __restrict__ dirs,
-                                                       int lights, int back_cull, int32_t* out_obj, int32_t* out_face,
-                                                       float* out_t, int32_t* out_dir, float* out_normal) {
+// closest hits for arbitrary rays (t3d_closest_hits); the second ray slot of every lane repeats the first
+__global__ __launch_bounds__(T3D_BLOCK) void k_closest(DevScene sc, GEO_PARAMS, int n, const float* __restrict__ origins,
+                                                       const float* __restrict__ dirs, int lights, int back_cull,
+                                                       int32_t* out_obj, int32_t* out_face, float* out_t, int32_t* out_dir,
+                                                       float* out_normal) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool active = i < n;
     int j = active ? i : 0;
     V3 o = mk(origins[3 * j], origins[3 * j + 1], origins[3 * j + 2]);
     V3 d = normalize(mk(dirs[3 * j], dirs[3 * j + 1], dirs[3 * j + 2]));
-    Hit h = closest_hit(tri_rows, sc.n_tris, spheres, sc.n_spheres, o, d, lights != 0, back_cull != 0);
+    Hit h, h_dup;
+    closest_hit2(GEO_ARGS, sc.n_planes, sc.n_tris, sc.n_spheres, o, d, o, d, lights != 0, back_cull != 0, back_cull != 0, h, h_dup);
     if (!active) return;
     int obj = -1, face = -1, dirflag = 0;
     V3 N = mk(0, 0, 0);
     if (h.prim >= 0) {
         if (h.prim < sc.n_tris) {
             int4 meta = sc.tri_meta[h.prim];
-            float4 rn = tri_rows[3 * h.prim];
+            float4 rn = sc.tri_n[h.prim];
             obj = meta.x; face = meta.y; N = mk(rn.x, rn.y, rn.z);
             dirflag = (dot(N, d) < 0.0f) ? 0 : 1;
         } else {
@@ -789,7 +762,8 @@ struct t3d_ctx {
     int n_sm = 256;
     // scene buffers
     DevScene sc{};
-    void* d_tri_rows = nullptr; void* d_tri_meta = nullptr; void* d_spheres = nullptr; void* d_lights = nullptr;
+    void* d_planes = nullptr; void* d_plane_first = nullptr; void* d_tri_uv = nullptr; void* d_tri_n = nullptr;
+    void* d_tri_meta = nullptr; void* d_spheres = nullptr; void* d_lights = nullptr;
     void* d_shaders = nullptr; void* d_obj_ior = nullptr;
     int n_objects = 0, n_sphere_objs = 0, n_light_objs = 0;
     // work buffers
@@ -858,9 +832,11 @@ extern "C" int t3d_create(int device, t3d_ctx** out) {
 }
 
 static void free_scene(t3d_ctx* c) {
-    hipFree(c->d_tri_rows); hipFree(c->d_tri_meta); hipFree(c->d_spheres); hipFree(c->d_lights);
+    hipFree(c->d_planes); hipFree(c->d_plane_first); hipFree(c->d_tri_uv); hipFree(c->d_tri_n);
+    hipFree(c->d_tri_meta); hipFree(c->d_spheres); hipFree(c->d_lights);
     hipFree(c->d_shaders); hipFree(c->d_obj_ior);
-    c->d_tri_rows = c->d_tri_meta = c->d_spheres = c->d_lights = c->d_shaders = c->d_obj_ior = nullptr;
+    c->d_planes = c->d_plane_first = c->d_tri_uv = c->d_tri_n = nullptr;
+    c->d_tri_meta = c->d_spheres = c->d_lights = c->d_shaders = c->d_obj_ior = nullptr;
     c->has_scene = false;
 }
 static void free_work(t3d_ctx* c) {
@@ -897,10 +873,16 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_scene(c);
 
-    std::vector<float4> rows((size_t)3 * s->n_tris);
-    std::vector<int4> meta((size_t)s->n_tris);
+    // Triangles are grouped by supporting plane (same unit normal to 1e-7 and same offset to 1e-6, float64):
+    // groups in order of their first triangle, triangles inside a group in their original order.
+    struct Tri { int obj, face, shader; double n[3], nv0, a[4], b[4]; };
+    std::vector<Tri> tris((size_t)s->n_tris);
+    std::vector<int> group_of((size_t)s->n_tris, -1);
+    std::vector<std::vector<int>> groups;
+    std::map<std::tuple<long long, long long, long long, long long>, int> plane_index;
     std::vector<DevSphere> spheres;
     std::vector<float> obj_ior((size_t)s->n_objects);
+    std::vector<char> seen((size_t)s->n_tris, 0);
     c->n_sphere_objs = c->n_light_objs = 0;
     for (int o = 0; o < s->n_objects; ++o) {
         obj_ior[o] = (float)s->obj_ior[o];
@@ -915,15 +897,28 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
                 double nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
                 double nn = nx * nx + ny * ny + nz * nz;
                 double inv = nn > 0 ? 1.0 / nn : 0.0;
+                Tri& T = tris[t];
                 // a = (e2 x n) / |n|^2, b = (n x e1) / |n|^2 :  P - v0 = u e1 + v e2
-                double ax = (e2[1] * nz - e2[2] * ny) * inv, ay = (e2[2] * nx - e2[0] * nz) * inv, az = (e2[0] * ny - e2[1] * nx) * inv;
-                double bx = (ny * e1[2] - nz * e1[1]) * inv, by = (nz * e1[0] - nx * e1[2]) * inv, bz = (nx * e1[1] - ny * e1[0]) * inv;
-                rows[3 * (size_t)t + 0] = make_float4((float)nx, (float)ny, (float)nz, (float)(nx * v[0] + ny * v[1] + nz * v[2]));
-                rows[3 * (size_t)t + 1] = make_float4((float)ax, (float)ay, (float)az, (float)(-(ax * v[0] + ay * v[1] + az * v[2])));
-                rows[3 * (size_t)t + 2] = make_float4((float)bx, (float)by, (float)bz, (float)(-(bx * v[0] + by * v[1] + bz * v[2])));
-                int sh = s->tri_shader[t];
-                if (sh < 0 || sh >= s->n_shaders) { c->err = "t3d_upload_scene: triangle shader index out of range"; return T3D_E_INVALID; }
-                meta[t] = make_int4(o, k, sh, 0);
+                T.a[0] = (e2[1] * nz - e2[2] * ny) * inv; T.a[1] = (e2[2] * nx - e2[0] * nz) * inv; T.a[2] = (e2[0] * ny - e2[1] * nx) * inv;
+                T.b[0] = (ny * e1[2] - nz * e1[1]) * inv; T.b[1] = (nz * e1[0] - nx * e1[2]) * inv; T.b[2] = (nx * e1[1] - ny * e1[0]) * inv;
+                T.a[3] = -(T.a[0] * v[0] + T.a[1] * v[1] + T.a[2] * v[2]);
+                T.b[3] = -(T.b[0] * v[0] + T.b[1] * v[1] + T.b[2] * v[2]);
+                T.n[0] = nx; T.n[1] = ny; T.n[2] = nz; T.nv0 = nx * v[0] + ny * v[1] + nz * v[2];
+                T.obj = o; T.face = k; T.shader = s->tri_shader[t];
+                if (T.shader < 0 || T.shader >= s->n_shaders) { c->err = "t3d_upload_scene: triangle shader index out of range"; return T3D_E_INVALID; }
+                if (seen[t]) { c->err = "t3d_upload_scene: triangle ranges of two objects overlap"; return T3D_E_INVALID; }
+                seen[t] = 1;
+                int g = -1;
+                if (nn > 0) {
+                    double len = sqrt(nn), off = T.nv0 / len;
+                    auto key = std::make_tuple(llround(nx / len * 1e7), llround(ny / len * 1e7), llround(nz / len * 1e7),
+                                               llround(off * 1e6));
+                    auto it = plane_index.find(key);
+                    if (it == plane_index.end()) { g = (int)groups.size(); plane_index.emplace(key, g); groups.emplace_back(); }
+                    else g = it->second;
+                } else { g = (int)groups.size(); groups.emplace_back(); }  // degenerate triangle: never hit, own group
+                groups[g].push_back(t);
+                group_of[t] = g;
             }
         } else if (ty == T3D_OBJ_SPHERE || ty == T3D_OBJ_LIGHT) {
             DevSphere sp;
@@ -935,6 +930,31 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
             spheres.push_back(sp);
             if (sp.is_light) c->n_light_objs++; else c->n_sphere_objs++;
         }
+    }
+    int n_mesh_tris = 0;
+    for (auto& g : groups) n_mesh_tris += (int)g.size();
+    if (n_mesh_tris != s->n_tris) { c->err = "t3d_upload_scene: triangles not owned by any mesh object"; return T3D_E_INVALID; }
+    std::vector<float4> planes(groups.size() + 1, make_float4(0.f, 0.f, 0.f, 0.f));
+    std::vector<int> plane_first(groups.size() + 1, 0);
+    std::vector<float4> tri_uv((size_t)2 * (s->n_tris + 1), make_float4(0.f, 0.f, 0.f, 0.f));
+    std::vector<float4> tri_n((size_t)s->n_tris + 1, make_float4(0.f, 0.f, 0.f, 0.f));
+    std::vector<int4> meta((size_t)s->n_tris + 1, make_int4(0, 0, 0, 0));
+    {
+        int k = 0;
+        for (size_t g = 0; g < groups.size(); ++g) {
+            const Tri& F = tris[groups[g][0]];
+            planes[g] = make_float4((float)F.n[0], (float)F.n[1], (float)F.n[2], (float)F.nv0);
+            plane_first[g] = k;
+            for (int t : groups[g]) {
+                const Tri& T = tris[t];
+                tri_uv[2 * (size_t)k + 0] = make_float4((float)T.a[0], (float)T.a[1], (float)T.a[2], (float)T.a[3]);
+                tri_uv[2 * (size_t)k + 1] = make_float4((float)T.b[0], (float)T.b[1], (float)T.b[2], (float)T.b[3]);
+                tri_n[k] = make_float4((float)T.n[0], (float)T.n[1], (float)T.n[2], 0.f);
+                meta[k] = make_int4(T.obj, T.face, T.shader, t);
+                ++k;
+            }
+        }
+        plane_first[groups.size()] = k;
     }
     std::vector<DevShader> shaders((size_t)s->n_shaders);
     for (int k = 0; k < s->n_shaders; ++k) {
@@ -948,12 +968,13 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
         for (int ch = 0; ch < 3; ++ch) { lc[ch] += s->light_color[3 * l + ch] * 0.6; if (lc[ch] > 255) lc[ch] = 255; }
     }
     int rc;
-    if ((rc = upload(c, &c->d_tri_rows, rows)) || (rc = upload(c, &c->d_tri_meta, meta)) || (rc = upload(c, &c->d_spheres, spheres)) ||
+    if ((rc = upload(c, &c->d_planes, planes)) || (rc = upload(c, &c->d_plane_first, plane_first)) || (rc = upload(c, &c->d_tri_uv, tri_uv)) ||
+        (rc = upload(c, &c->d_tri_n, tri_n)) || (rc = upload(c, &c->d_tri_meta, meta)) || (rc = upload(c, &c->d_spheres, spheres)) ||
         (rc = upload(c, &c->d_lights, lights)) || (rc = upload(c, &c->d_shaders, shaders)) || (rc = upload(c, &c->d_obj_ior, obj_ior)))
         return rc;
     DevScene& d = c->sc;
-    d.n_tris = s->n_tris; d.n_spheres = (int)spheres.size(); d.n_lights = s->n_lights; d.n_shaders = s->n_shaders;
-    d.tri_rows = (const float4*)c->d_tri_rows; d.tri_meta = (const int4*)c->d_tri_meta; d.spheres = (const DevSphere*)c->d_spheres;
+    d.n_planes = (int)groups.size(); d.n_tris = s->n_tris; d.n_spheres = (int)spheres.size(); d.n_lights = s->n_lights; d.n_shaders = s->n_shaders;
+    d.tri_n = (const float4*)c->d_tri_n; d.tri_meta = (const int4*)c->d_tri_meta;
     d.lights = (const DevLight*)c->d_lights; d.shaders = (const DevShader*)c->d_shaders; d.obj_ior = (const float*)c->d_obj_ior;
     for (int k = 0; k < 3; ++k) { d.cam.pos[k] = (float)s->cam_pos[k]; d.light_color[k] = (float)lc[k]; }
     {   // Euler.toMatrix (T3DE.py:70-94) in float64, rounded once
@@ -1070,9 +1091,9 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
     const int max_blocks = c->n_sm * 8;
     auto blocks_for = [&](size_t n) { size_t b = (n + T3D_BLOCK - 1) / T3D_BLOCK; return (int)(b < 1 ? 1 : (b > (size_t)max_blocks ? (size_t)max_blocks : b)); };
     // grids of the sharded kernels hold a multiple of T3D_SHARDS waves
-    const size_t grid_unit = T3D_SHARDS / (T3D_TRACE_BLOCK / 64);
+    const size_t grid_unit = T3D_SHARDS / (T3D_BLOCK / 64);
     auto trace_blocks_for = [&](size_t n) {
-        size_t b = (n + T3D_TRACE_BLOCK - 1) / T3D_TRACE_BLOCK, mx = (size_t)c->n_sm * (2048 / T3D_TRACE_BLOCK);
+        size_t b = (n + T3D_BLOCK - 1) / T3D_BLOCK, mx = (size_t)c->n_sm * (2048 / T3D_BLOCK);
         b = b > mx ? mx : b;
         b = (b + grid_unit - 1) / grid_unit * grid_unit;
         return (int)b;
@@ -1081,21 +1102,23 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
     // per-launch timing: event d+1 after k_level(d); read by fill_stats
     int n_timed = 0;
     auto tick = [&]() -> hipError_t { return hipEventRecord(c->ev[n_timed++], st); };
-    const float4* rows = (const float4*)c->d_tri_rows;
+    const float4* planes = (const float4*)c->d_planes;
+    const int* pfirst = (const int*)c->d_plane_first;
+    const float4* uv = (const float4*)c->d_tri_uv;
     const DevSphere* sph = (const DevSphere*)c->d_spheres;
     HIPCHK(c, tick());  // ev[0]: start of the call
     for (int d = 0; d < levels; ++d) {
         RayRec* in = c->d_rays[d & 1];
         RayRec* outq = c->d_rays[(d + 1) & 1];
         if (d == 0)
-            hipLaunchKernelGGL(k_level<true>, dim3(trace_blocks_for(n0)), dim3(T3D_TRACE_BLOCK), 0, st, c->sc, rows, sph, rp, d, in, outq, c->pool, c->d_cnt, out);
+            hipLaunchKernelGGL(k_level<true>, dim3(trace_blocks_for(n0)), dim3(T3D_BLOCK), 0, st, c->sc, planes, pfirst, uv, sph, rp, d, in, outq, c->pool, c->d_cnt, out);
         else
-            hipLaunchKernelGGL(k_level<false>, dim3(single ? (int)grid_unit : trace_blocks_for(c->cap_alloc)), dim3(T3D_TRACE_BLOCK), 0, st, c->sc, rows, sph, rp, d, in, outq, c->pool, c->d_cnt, out);
+            hipLaunchKernelGGL(k_level<false>, dim3(single ? (int)grid_unit : trace_blocks_for(c->cap_alloc)), dim3(T3D_BLOCK), 0, st, c->sc, planes, pfirst, uv, sph, rp, d, in, outq, c->pool, c->d_cnt, out);
         HIPCHK(c, tick());  // ev[1 + d]: k_level(d) done
         launches += 1;
     }
     for (int d = levels - 1; d >= 0; --d) {
-        hipLaunchKernelGGL(k_resolve, dim3(single ? (int)grid_unit : trace_blocks_for(c->cap_alloc)), dim3(T3D_TRACE_BLOCK), 0, st, c->sc, rp, d, c->pool, c->d_cnt,
+        hipLaunchKernelGGL(k_resolve, dim3(single ? (int)grid_unit : trace_blocks_for(c->cap_alloc)), dim3(T3D_BLOCK), 0, st, c->sc, rp, d, c->pool, c->d_cnt,
                            c->d_sample_color, d_dbg, dbg_cap);
         launches++;
     }
@@ -1264,8 +1287,8 @@ extern "C" int t3d_closest_hits(t3d_ctx* c, int n, const float* origins, const f
     CH(hipMalloc((void**)&d_obj, n * sizeof(int32_t))); CH(hipMalloc((void**)&d_face, n * sizeof(int32_t))); CH(hipMalloc((void**)&d_dir, n * sizeof(int32_t)));
     CH(hipMemcpyAsync(d_o, origins, n3, hipMemcpyHostToDevice, c->stream));
     CH(hipMemcpyAsync(d_d, dirs, n3, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_closest, dim3((n + T3D_BLOCK - 1) / T3D_BLOCK), dim3(T3D_BLOCK), 0, c->stream, c->sc, (const float4*)c->d_tri_rows,
-                       (const DevSphere*)c->d_spheres, n, d_o, d_d, lights, back_cull, d_obj, d_face, d_t, d_dir, d_n);
+    hipLaunchKernelGGL(k_closest, dim3((n + T3D_BLOCK - 1) / T3D_BLOCK), dim3(T3D_BLOCK), 0, c->stream, c->sc, (const float4*)c->d_planes,
+                       (const int*)c->d_plane_first, (const float4*)c->d_tri_uv, (const DevSphere*)c->d_spheres, n, d_o, d_d, lights, back_cull, d_obj, d_face, d_t, d_dir, d_n);
     CH(hipGetLastError());
     CH(hipMemcpyAsync(out_obj, d_obj, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     CH(hipMemcpyAsync(out_face, d_face, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));

@@ -1,0 +1,24 @@
+import os, sys, json
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from raytracing_amd.scene import Scene
+from raytracing_amd.flatten import flatten_scene
+from raytracing_amd import _native
+from oracle import oracle
+flat = flatten_scene(Scene.fromJSON(os.path.join(ROOT, "tests/golden/scenes/cornellScene.json")))
+ctx = _native.Context(0); ctx.upload(flat)
+opt = dict(width=160, height=120, bounces=0)
+for (px, py) in [(80, 99), (84, 99), (70, 99)]:
+    pv, s, d = oracle.camera_ray(flat, opt, px, py)
+    h = oracle.first_collision(flat, s, d, True, True)
+    g = ctx.closest_hits([s], [d], True, True)
+    print("pixel", px, py, "oracle", h["obj"], h["face"], h["t"], "gpu", g["obj"][0], g["face"][0], g["t"][0])
+    P = np.array(h["point"])
+    for l in range(len(flat.light_strength)):
+        to = flat.light_pos[l] - P
+        Ld = to / np.linalg.norm(to)
+        st = P + 0.2 * Ld
+        ho = oracle.first_collision(flat, st, Ld, True, False)
+        hg = ctx.closest_hits([st], [Ld], True, False)
+        print("   light", l, "oracle", ho["obj"], ho["face"], round(ho["t"], 5), ho["direction"], " gpu", hg["obj"][0], hg["face"][0], hg["t"][0], hg["direction"][0])
