@@ -192,6 +192,14 @@ int t3d_closest_hits(t3d_ctx* ctx, int n, const float* origins, const float* dir
  */
 int t3d_last_call_stats(t3d_ctx* ctx, t3d_stats* stats);
 
+/*
+ * Per-kernel timing on (default) / off.  When on, an event is recorded after every k_level launch so
+ * that t3d_stats::ms_k_level and ms_resolve are filled; each event costs a few microseconds of stream
+ * idle time between two launches.  When off only ms_device (whole call) is measured and the other two
+ * stay 0.  No counterpart in the reference.
+ */
+int t3d_set_timing(t3d_ctx* ctx, int per_kernel);
+
 int t3d_abi_version(void);
 
 #ifdef __cplusplus

@@ -80,15 +80,21 @@ struct DevCamera {
 
 // Geometry streamed by every closest-hit query; passed as separate __restrict__ kernel arguments so
 // that the compiler may use scalar loads for it.
-//   planes      [G]   (n.xyz, n.v0) of the first triangle of each coplanar group, un-normalised like
+//   planes      [G]   (n.x, -n.v0, n.y, n.z) of the first triangle of each coplanar group, un-normalised like
 //                     MathematicalPlane.normal (T3DE.py:251-263)
 //   plane_first [G+1] triangle range of each group
-//   tri_uv      [2T]  per triangle (a.xyz, aw), (b.xyz, bw): P - v0 = u e1 + v e2, prepared in float64
+//   tri_uv      [2T]  per triangle (a_s, aw, a_t, 0), (b_s, bw, b_t, 0): barycentric rows in the two in-plane
+//                     coordinates (s, t) left after dropping the group's dominant axis, prepared in float64
 #define GEO_PARAMS const float4* __restrict__ planes, const int* __restrict__ plane_first, \
                    const float4* __restrict__ tri_uv, const DevSphere* __restrict__ spheres
 #define GEO_ARGS planes, plane_first, tri_uv, spheres
 
+struct DevGeo {
+    int axis_end[3];  // plane groups [0, axis_end[0]) have their largest normal component along x, then y, then z
+    int n_tris, n_spheres;
+};
 struct DevScene {
+    DevGeo geo;
     int n_planes, n_tris, n_spheres, n_lights, n_shaders;
     const float4* tri_n;       // [T]: the triangle's own un-normalised normal (w unused)
     const int4* tri_meta;      // [T]: (object, face-in-mesh, shader, unused); triangles in plane-group order
@@ -194,63 +200,101 @@ struct Hit {
     int back;  // sphere: 1 = hit from inside
 };
 
-// Per plane group (getFaceCollision, T3DR.py:624-651):  d.n, t = (n.v0 - n.o) / (d.n), P = o + t d, and the
-// plane-level rejections folded into one value:
-//     pm = min((d.n)^2 - 1e-12, cull - d.n) > 0   <=>   |d.n| > 1e-6 and (d.n < 0 or both sides count)
-// (cull = 0 when back faces are rejected, +inf otherwise; packed instructions have no |x| modifier, hence
-// the square).  tp = pm > 0 ? t : +inf.
-// Per triangle of the group: u, v, w = 1-u-v; inside <=> min3(u, v, w) > 0 (strict: edges miss).
-// Distances are compared as UNSIGNED integer bit patterns: bits(tt) < bits(best) holds exactly for
-// 0 <= tt < best and fails for negative, +inf and NaN values, so "t >= 0" needs no test of its own.
-// Groups and triangles are visited so that the lowest original triangle index wins equal distances
-// (the reference keeps the first hit tested, T3DR.py:715).  A group whose plane cannot beat the current
-// best of any lane is skipped for the whole wave.
-__device__ __forceinline__ void closest_hit2(GEO_PARAMS, int n_planes, int n_tris, int n_spheres, V3 o0, V3 d0, V3 o1, V3 d1,
+// 1 where m * 2^126 >= 1, 0 where m <= 0, per component: one packed multiply with the clamp modifier (the
+// compiler does not fold a clamp into packed FP32 instructions; it does add the wait state a packed FP32
+// result needs before its next use after the asm block).
+__device__ __forceinline__ f2 step01(f2 m, f2 big) {
+    f2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(m), "s"(big));
+    return r;
+}
+
+// Plane groups whose normal is largest along axis AX (getFaceCollision, T3DR.py:624-651).
+// Per group:  d.n,  q = n.o - n.v0,  and the plane-level rejections folded into the divisor:
+//     ok = step01(min((d.n)^2 - 1e-12, cull - d.n))      |d.n| > 1e-6 and (d.n < 0 or both sides count)
+//     t  = -q / (d.n * ok)                               rejected planes divide by zero: t = +-inf or NaN
+// (cull = 0 when back faces are rejected, +inf otherwise; packed instructions have no |x| modifier, hence the
+// square).  Distances are compared as UNSIGNED integer bit patterns: bits(t) < bits(best) holds exactly for
+// 0 <= t < best and fails for negative, infinite and NaN values, so neither "t >= 0" nor the rejections need a
+// test of their own.  A group whose plane cannot beat the current best of any lane is skipped by the whole wave.
+// Per triangle of the group, in the two coordinates (s, t) that remain after dropping axis AX:
+//     u = a.(Ps, Pt) + aw,  v = b.(Ps, Pt) + bw,  w = 1 - u - v;   inside <=> min3(u, v, w) > 0 (strict: edges miss)
+// The hit flags of a group (at most 24 triangles) are collected as the bits of an integer kept in a float:
+//     A = 2 A + step01(min3(u, v, w))
+// so its highest set bit is the FIRST triangle hit, which is the one the reference keeps (T3DR.py:715).
+template <int AX>
+__device__ __forceinline__ void plane_groups(const float4* __restrict__ planes, const int* __restrict__ plane_first,
+                                             const float4* __restrict__ tri_uv, int g_begin, int g_end, f2 ox, f2 oy, f2 oz,
+                                             f2 dx, f2 dy, f2 dz, f2 cull, f2 big, uint32_t& best0, uint32_t& best1, float& A0,
+                                             float& A1, int& bg0, int& bg1) {
+    const f2 os = AX == 0 ? oy : (AX == 1 ? oz : ox), ot = AX == 0 ? oz : (AX == 1 ? ox : oy);
+    const f2 ds = AX == 0 ? dy : (AX == 1 ? dz : dx), dt = AX == 0 ? dz : (AX == 1 ? dx : dy);
+    for (int g = g_begin; g < g_end; ++g) {
+        const float4 rn = planes[g];
+        const f2 dn = fma2(splat(rn.w), dz, fma2(splat(rn.z), dy, splat(rn.x) * dx));
+        const f2 q = fma2(splat(rn.w), oz, fma2(splat(rn.z), oy, fma2(splat(rn.x), ox, splat(rn.y))));  // n.o - n.v0
+        const f2 e = fma2(dn, dn, splat(-1e-12f));
+        const f2 c = cull - dn;
+        const f2 mn = {fminf(e.x, c.x), fminf(e.y, c.y)};
+        const f2 dnv = dn * step01(mn, big);
+        const f2 inv = {__builtin_amdgcn_rcpf(dnv.x), __builtin_amdgcn_rcpf(dnv.y)};
+        const f2 t = -q * inv;
+        const uint32_t tp0 = __float_as_uint(t.x), tp1 = __float_as_uint(t.y);
+        if (!__any((tp0 < best0) | (tp1 < best1))) continue;  // wave-uniform
+        const int k0 = plane_first[g], k1 = plane_first[g + 1];
+        const f2 ps = fma2(ds, t, os), pt = fma2(dt, t, ot);
+        f2 A = splat(0.0f);
+        for (int k = k0; k < k1; ++k) {
+            const float4 ra = tri_uv[2 * k + 0];
+            const float4 rb = tri_uv[2 * k + 1];
+            const f2 u = fma2(splat(ra.z), pt, fma2(splat(ra.x), ps, splat(ra.y)));
+            const f2 v = fma2(splat(rb.z), pt, fma2(splat(rb.x), ps, splat(rb.y)));
+            const f2 w = (splat(1.0f) - u) - v;
+            const f2 m = {fminf(fminf(u.x, v.x), w.x), fminf(fminf(u.y, v.y), w.y)};
+            A = fma2(A, splat(2.0f), step01(m, big));
+        }
+        const uint32_t tt0 = (A.x >= 1.0f) ? tp0 : 0x7f800000u;
+        const uint32_t tt1 = (A.y >= 1.0f) ? tp1 : 0x7f800000u;
+        const bool cl0 = tt0 < best0, cl1 = tt1 < best1;
+        best0 = cl0 ? tt0 : best0; A0 = cl0 ? A.x : A0; bg0 = cl0 ? g : bg0;
+        best1 = cl1 ? tt1 : best1; A1 = cl1 ? A.y : A1; bg1 = cl1 ? g : bg1;
+    }
+}
+
+// Triangle index from the hit bits of its group: bit (n-1-j) stands for the j-th triangle of the group.
+__device__ __forceinline__ int first_hit_of_group(const int* __restrict__ plane_first, int g, float A) {
+    const int k0 = plane_first[g], n = plane_first[g + 1] - k0;
+    int j = n - 1 - ((int)(__float_as_uint(A) >> 23) - 127);
+    j = j < 0 ? 0 : (j > n - 1 ? n - 1 : j);
+    return k0 + j;
+}
+
+__device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0, V3 d0, V3 o1, V3 d1,
                                              bool lights, bool back_cull0, bool back_cull1, Hit& out0, Hit& out1) {
     const uint32_t INF_BITS = 0x7f800000u;
     const f2 ox = {o0.x, o1.x}, oy = {o0.y, o1.y}, oz = {o0.z, o1.z};
     const f2 dx = {d0.x, d1.x}, dy = {d0.y, d1.y}, dz = {d0.z, d1.z};
     const f2 cull = {back_cull0 ? 0.0f : __builtin_inff(), back_cull1 ? 0.0f : __builtin_inff()};
+    const f2 big = splat(0x1p126f);
     uint32_t best0 = INF_BITS, best1 = INF_BITS;
+    float A0 = 0.0f, A1 = 0.0f;
+    int bg0 = 0, bg1 = 0;
+    plane_groups<0>(planes, plane_first, tri_uv, 0, geo.axis_end[0], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1);
+    plane_groups<1>(planes, plane_first, tri_uv, geo.axis_end[0], geo.axis_end[1], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1);
+    plane_groups<2>(planes, plane_first, tri_uv, geo.axis_end[1], geo.axis_end[2], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1);
     int prim0 = -1, prim1 = -1, back0 = 0, back1 = 0;
-    for (int g = 0; g < n_planes; ++g) {
-        const float4 rn = planes[g];
-        const int k0 = plane_first[g], k1 = plane_first[g + 1];
-        const f2 dn = fma2(splat(rn.z), dz, fma2(splat(rn.y), dy, splat(rn.x) * dx));
-        const f2 q = fma2(splat(rn.z), oz, fma2(splat(rn.y), oy, fma2(splat(rn.x), ox, splat(-rn.w))));  // n.o - n.v0
-        const f2 inv = {__builtin_amdgcn_rcpf(dn.x), __builtin_amdgcn_rcpf(dn.y)};
-        const f2 t = -q * inv;
-        const f2 e = fma2(dn, dn, splat(-1e-12f));
-        const f2 c = cull - dn;
-        const uint32_t tp0 = (fminf(e.x, c.x) > 0.0f) ? __float_as_uint(t.x) : INF_BITS;
-        const uint32_t tp1 = (fminf(e.y, c.y) > 0.0f) ? __float_as_uint(t.y) : INF_BITS;
-        if (!__any((tp0 < best0) | (tp1 < best1))) continue;  // wave-uniform
-        const f2 px = fma2(dx, t, ox), py = fma2(dy, t, oy), pz = fma2(dz, t, oz);
-        int hit0 = -1, hit1 = -1;
-        for (int k = k1 - 1; k >= k0; --k) {
-            const float4 ra = tri_uv[2 * k + 0];
-            const float4 rb = tri_uv[2 * k + 1];
-            const f2 u = fma2(splat(ra.z), pz, fma2(splat(ra.y), py, fma2(splat(ra.x), px, splat(ra.w))));
-            const f2 v = fma2(splat(rb.z), pz, fma2(splat(rb.y), py, fma2(splat(rb.x), px, splat(rb.w))));
-            const f2 w = (splat(1.0f) - u) - v;
-            hit0 = (fminf(fminf(u.x, v.x), w.x) > 0.0f) ? k : hit0;
-            hit1 = (fminf(fminf(u.y, v.y), w.y) > 0.0f) ? k : hit1;
-        }
-        const uint32_t tt0 = (hit0 >= 0) ? tp0 : INF_BITS;
-        const uint32_t tt1 = (hit1 >= 0) ? tp1 : INF_BITS;
-        const bool cl0 = tt0 < best0, cl1 = tt1 < best1;
-        best0 = cl0 ? tt0 : best0; prim0 = cl0 ? hit0 : prim0;
-        best1 = cl1 ? tt1 : best1; prim1 = cl1 ? hit1 : prim1;
-    }
+    if (best0 < INF_BITS) prim0 = first_hit_of_group(plane_first, bg0, A0);
+    if (best1 < INF_BITS) prim1 = first_hit_of_group(plane_first, bg1, A1);
     // Spheres and lights.  getSphereCollision (T3DR.py:572-598), Ray.getTSphere (T3DE.py:145-163).
-    for (int s = 0; s < n_spheres; ++s) {
+    const int n_tris = geo.n_tris;
+    for (int s = 0; s < geo.n_spheres; ++s) {
         const DevSphere sp = spheres[s];
         if (sp.is_light && !lights) continue;  // wave-uniform
         const f2 Lx = ox - splat(sp.cx), Ly = oy - splat(sp.cy), Lz = oz - splat(sp.cz);
         const f2 b = fma2(Lz, dz, fma2(Ly, dy, Lx * dx));
         const f2 cc = fma2(Lz, Lz, fma2(Ly, Ly, Lx * Lx)) - splat(sp.r2);
         const f2 disc = fma2(b, b, -cc);
-        const f2 root = {__builtin_sqrtf(fmaxf(disc.x, 0.0f)), __builtin_sqrtf(fmaxf(disc.y, 0.0f))};
+        const f2 root = {__builtin_amdgcn_sqrtf(fmaxf(disc.x, 0.0f)), __builtin_amdgcn_sqrtf(fmaxf(disc.y, 0.0f))};
         const f2 t1 = -b - root, t2 = -b + root;
         {
             const bool front = t1.x > 0.0f;
@@ -622,7 +666,7 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_level(DevScene sc, GEO_PARAMS, Re
             const ShadowRay s0 = shadow_ray(sc, ring_a[nd0 % T3D_RING], rb0, l0);
             const ShadowRay s1 = shadow_ray(sc, ring_a[nd1 % T3D_RING], rb1, l1);
             Hit h0, h1;
-            closest_hit2(GEO_ARGS, sc.n_planes, sc.n_tris, sc.n_spheres, s0.start, s0.Ld, s1.start, s1.Ld, true, false, false, h0, h1);
+            closest_hit2(GEO_ARGS, sc.geo, s0.start, s0.Ld, s1.start, s1.Ld, true, false, false, h0, h1);
             const float I0 = shadow_intensity(sc, spheres, s0, h0), I1 = shadow_intensity(sc, spheres, s1, h1);
             if (run0) pool.li[(wc.node_base + (size_t)__float_as_int(rb0.w)) * L + l0] = I0;
             if (run1) pool.li[(wc.node_base + (size_t)__float_as_int(rb1.w)) * L + l1] = I1;
@@ -634,7 +678,7 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_level(DevScene sc, GEO_PARAMS, Re
             load_ray<LEVEL0>(sc, rp, rays_in, chunk * 128 + 64 + wc.lane, n_in, queue_base, in1);
             const bool lights = LEVEL0 ? (rp.lights != 0) : true;
             Hit h0, h1;
-            closest_hit2(GEO_ARGS, sc.n_planes, sc.n_tris, sc.n_spheres, in0.o, in0.d, in1.o, in1.d, lights,
+            closest_hit2(GEO_ARGS, sc.geo, in0.o, in0.d, in1.o, in1.d, lights,
                          in0.ior == 1.0f, in1.ior == 1.0f, h0, h1);  // back faces culled iff ray.ior == 1 (T3DR.py:961)
             process_ray<LEVEL0>(sc, spheres, rp, wc, in0, h0, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes);
             process_ray<LEVEL0>(sc, spheres, rp, wc, in1, h1, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes);
@@ -728,7 +772,7 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_closest(DevScene sc, GEO_PARAMS, 
     V3 o = mk(origins[3 * j], origins[3 * j + 1], origins[3 * j + 2]);
     V3 d = normalize(mk(dirs[3 * j], dirs[3 * j + 1], dirs[3 * j + 2]));
     Hit h, h_dup;
-    closest_hit2(GEO_ARGS, sc.n_planes, sc.n_tris, sc.n_spheres, o, d, o, d, lights != 0, back_cull != 0, back_cull != 0, h, h_dup);
+    closest_hit2(GEO_ARGS, sc.geo, o, d, o, d, lights != 0, back_cull != 0, back_cull != 0, h, h_dup);
     if (!active) return;
     int obj = -1, face = -1, dirflag = 0;
     V3 N = mk(0, 0, 0);
@@ -779,6 +823,8 @@ struct t3d_ctx {
     uint8_t* d_bgr = nullptr; float* d_rad = nullptr; int32_t* d_prim = nullptr; float* d_prim_t = nullptr;
     size_t mem_budget = (size_t)48 << 30;
     // the most recent band, for t3d_last_call_stats
+    bool timing = true;       // record an event after every k_level launch (t3d_set_timing)
+    bool last_timed = true;
     bool last_valid = false; int last_levels = 0; size_t last_n0 = 0; int last_lights = 1; uint64_t last_launches = 0;
     hipStream_t last_stream = nullptr;
 };
@@ -875,7 +921,7 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
 
     // Triangles are grouped by supporting plane (same unit normal to 1e-7 and same offset to 1e-6, float64):
     // groups in order of their first triangle, triangles inside a group in their original order.
-    struct Tri { int obj, face, shader; double n[3], nv0, a[4], b[4]; };
+    struct Tri { int obj, face, shader; double n[3], nv0; };
     std::vector<Tri> tris((size_t)s->n_tris);
     std::vector<int> group_of((size_t)s->n_tris, -1);
     std::vector<std::vector<int>> groups;
@@ -896,13 +942,7 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
                 double e1[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]}, e2[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]};
                 double nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
                 double nn = nx * nx + ny * ny + nz * nz;
-                double inv = nn > 0 ? 1.0 / nn : 0.0;
                 Tri& T = tris[t];
-                // a = (e2 x n) / |n|^2, b = (n x e1) / |n|^2 :  P - v0 = u e1 + v e2
-                T.a[0] = (e2[1] * nz - e2[2] * ny) * inv; T.a[1] = (e2[2] * nx - e2[0] * nz) * inv; T.a[2] = (e2[0] * ny - e2[1] * nx) * inv;
-                T.b[0] = (ny * e1[2] - nz * e1[1]) * inv; T.b[1] = (nz * e1[0] - nx * e1[2]) * inv; T.b[2] = (nx * e1[1] - ny * e1[0]) * inv;
-                T.a[3] = -(T.a[0] * v[0] + T.a[1] * v[1] + T.a[2] * v[2]);
-                T.b[3] = -(T.b[0] * v[0] + T.b[1] * v[1] + T.b[2] * v[2]);
                 T.n[0] = nx; T.n[1] = ny; T.n[2] = nz; T.nv0 = nx * v[0] + ny * v[1] + nz * v[2];
                 T.obj = o; T.face = k; T.shader = s->tri_shader[t];
                 if (T.shader < 0 || T.shader >= s->n_shaders) { c->err = "t3d_upload_scene: triangle shader index out of range"; return T3D_E_INVALID; }
@@ -934,27 +974,61 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
     int n_mesh_tris = 0;
     for (auto& g : groups) n_mesh_tris += (int)g.size();
     if (n_mesh_tris != s->n_tris) { c->err = "t3d_upload_scene: triangles not owned by any mesh object"; return T3D_E_INVALID; }
-    std::vector<float4> planes(groups.size() + 1, make_float4(0.f, 0.f, 0.f, 0.f));
-    std::vector<int> plane_first(groups.size() + 1, 0);
+    // Device order of the groups: by the axis of the largest normal component (that axis is dropped for the
+    // in-plane coordinates), groups of one axis in order of their first triangle; groups of more than 24
+    // triangles are cut into pieces (the hit flags of a group are the bits of a float32 integer).
+    struct Piece { int group, first, count, axis; };
+    std::vector<Piece> pieces;
+    int axis_count[3] = {0, 0, 0};
+    for (int ax = 0; ax < 3; ++ax) {
+        for (size_t g = 0; g < groups.size(); ++g) {
+            const Tri& F = tris[groups[g][0]];
+            int gax = 0;
+            if (fabs(F.n[1]) > fabs(F.n[gax])) gax = 1;
+            if (fabs(F.n[2]) > fabs(F.n[gax])) gax = 2;
+            if (gax != ax) continue;
+            for (int first = 0; first < (int)groups[g].size(); first += 24) {
+                int cnt = (int)groups[g].size() - first;
+                pieces.push_back(Piece{(int)g, first, cnt > 24 ? 24 : cnt, ax});
+                axis_count[ax]++;
+            }
+        }
+    }
+    const size_t G = pieces.size();
+    std::vector<float4> planes(G + 1, make_float4(0.f, 0.f, 0.f, 0.f));
+    std::vector<int> plane_first(G + 1, 0);
     std::vector<float4> tri_uv((size_t)2 * (s->n_tris + 1), make_float4(0.f, 0.f, 0.f, 0.f));
     std::vector<float4> tri_n((size_t)s->n_tris + 1, make_float4(0.f, 0.f, 0.f, 0.f));
     std::vector<int4> meta((size_t)s->n_tris + 1, make_int4(0, 0, 0, 0));
     {
         int k = 0;
-        for (size_t g = 0; g < groups.size(); ++g) {
-            const Tri& F = tris[groups[g][0]];
-            planes[g] = make_float4((float)F.n[0], (float)F.n[1], (float)F.n[2], (float)F.nv0);
+        for (size_t g = 0; g < G; ++g) {
+            const Piece& pc = pieces[g];
+            const Tri& F = tris[groups[pc.group][0]];
+            // rows are stored (x, offset, y, z): the first fma of a dot product then takes its factor and its
+            // addend from one aligned SGPR pair; "+ 0.0f" turns a -0 offset into +0
+            planes[g] = make_float4((float)F.n[0], -(float)F.nv0 + 0.0f, (float)F.n[1], (float)F.n[2]);
             plane_first[g] = k;
-            for (int t : groups[g]) {
+            const int i1 = (pc.axis + 1) % 3, i2 = (pc.axis + 2) % 3;  // in-plane coordinates (s, t)
+            for (int j = 0; j < pc.count; ++j) {
+                const int t = groups[pc.group][pc.first + j];
                 const Tri& T = tris[t];
-                tri_uv[2 * (size_t)k + 0] = make_float4((float)T.a[0], (float)T.a[1], (float)T.a[2], (float)T.a[3]);
-                tri_uv[2 * (size_t)k + 1] = make_float4((float)T.b[0], (float)T.b[1], (float)T.b[2], (float)T.b[3]);
+                const double* v = s->tri_verts + 9 * (size_t)t;
+                const double e1s = v[3 + i1] - v[i1], e1t = v[3 + i2] - v[i2], e2s = v[6 + i1] - v[i1], e2t = v[6 + i2] - v[i2];
+                const double det = e1s * e2t - e2s * e1t;
+                if (det != 0.0) {
+                    // (Ps - v0s, Pt - v0t) = u (e1s, e1t) + v (e2s, e2t), solved in float64
+                    const double as = e2t / det, at = -e2s / det, bs = -e1t / det, bt = e1s / det;
+                    const double aw = -(as * v[i1] + at * v[i2]), bw = -(bs * v[i1] + bt * v[i2]);
+                    tri_uv[2 * (size_t)k + 0] = make_float4((float)as, (float)aw + 0.0f, (float)at, 0.f);
+                    tri_uv[2 * (size_t)k + 1] = make_float4((float)bs, (float)bw + 0.0f, (float)bt, 0.f);
+                }   // else: degenerate triangle, rows stay zero and min3(u, v, w) = 0 never counts as inside
                 tri_n[k] = make_float4((float)T.n[0], (float)T.n[1], (float)T.n[2], 0.f);
                 meta[k] = make_int4(T.obj, T.face, T.shader, t);
                 ++k;
             }
         }
-        plane_first[groups.size()] = k;
+        plane_first[G] = k;
     }
     std::vector<DevShader> shaders((size_t)s->n_shaders);
     for (int k = 0; k < s->n_shaders; ++k) {
@@ -973,7 +1047,9 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
         (rc = upload(c, &c->d_lights, lights)) || (rc = upload(c, &c->d_shaders, shaders)) || (rc = upload(c, &c->d_obj_ior, obj_ior)))
         return rc;
     DevScene& d = c->sc;
-    d.n_planes = (int)groups.size(); d.n_tris = s->n_tris; d.n_spheres = (int)spheres.size(); d.n_lights = s->n_lights; d.n_shaders = s->n_shaders;
+    d.geo.axis_end[0] = axis_count[0]; d.geo.axis_end[1] = axis_count[0] + axis_count[1]; d.geo.axis_end[2] = (int)G;
+    d.geo.n_tris = s->n_tris; d.geo.n_spheres = (int)spheres.size();
+    d.n_planes = (int)G; d.n_tris = s->n_tris; d.n_spheres = (int)spheres.size(); d.n_lights = s->n_lights; d.n_shaders = s->n_shaders;
     d.tri_n = (const float4*)c->d_tri_n; d.tri_meta = (const int4*)c->d_tri_meta;
     d.lights = (const DevLight*)c->d_lights; d.shaders = (const DevShader*)c->d_shaders; d.obj_ior = (const float*)c->d_obj_ior;
     for (int k = 0; k < 3; ++k) { d.cam.pos[k] = (float)s->cam_pos[k]; d.light_color[k] = (float)lc[k]; }
@@ -1031,16 +1107,18 @@ static int check_opts(t3d_ctx* c, const t3d_opts* o, int row0, int nrows) {
 // Counters and event timings of the most recent band; the stream must have been synchronised.
 static void fill_stats(t3d_ctx* c, t3d_stats* stats) {
     const int levels = c->last_levels;
-    const int n_ev = levels + 2;
+    const int n_ev = c->last_timed ? levels + 2 : 2;
     float ms = 0;
     hipEventElapsedTime(&ms, c->ev[0], c->ev[n_ev - 1]);
     stats->ms_device += ms;
-    for (int d = 0; d < levels; ++d) {
-        hipEventElapsedTime(&ms, c->ev[d], c->ev[d + 1]);
-        stats->ms_k_level += ms;
+    if (c->last_timed) {
+        for (int d = 0; d < levels; ++d) {
+            hipEventElapsedTime(&ms, c->ev[d], c->ev[d + 1]);
+            stats->ms_k_level += ms;
+        }
+        hipEventElapsedTime(&ms, c->ev[levels], c->ev[n_ev - 1]);
+        stats->ms_resolve += ms;
     }
-    hipEventElapsedTime(&ms, c->ev[levels], c->ev[n_ev - 1]);
-    stats->ms_resolve += ms;
     uint64_t rays = 0, nodes = 0;
     for (int d = 0; d < levels; ++d) {
         if (d == 0) rays += c->last_n0;
@@ -1114,7 +1192,7 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
             hipLaunchKernelGGL(k_level<true>, dim3(trace_blocks_for(n0)), dim3(T3D_BLOCK), 0, st, c->sc, planes, pfirst, uv, sph, rp, d, in, outq, c->pool, c->d_cnt, out);
         else
             hipLaunchKernelGGL(k_level<false>, dim3(single ? (int)grid_unit : trace_blocks_for(c->cap_alloc)), dim3(T3D_BLOCK), 0, st, c->sc, planes, pfirst, uv, sph, rp, d, in, outq, c->pool, c->d_cnt, out);
-        HIPCHK(c, tick());  // ev[1 + d]: k_level(d) done
+        if (c->timing) HIPCHK(c, tick());  // ev[1 + d]: k_level(d) done
         launches += 1;
     }
     for (int d = levels - 1; d >= 0; --d) {
@@ -1126,9 +1204,10 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
         hipLaunchKernelGGL(k_finish, dim3(blocks_for((size_t)nrows * o->width)), dim3(T3D_BLOCK), 0, st, rp, c->d_sample_color, d_bgr, d_rad);
         launches++;
     }
-    HIPCHK(c, tick());  // ev[1 + 2*levels]: end of the call
+    HIPCHK(c, tick());  // last event: end of the call
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
+    c->last_timed = c->timing;
     c->last_levels = levels; c->last_n0 = n0; c->last_lights = o->lights; c->last_launches = launches; c->last_stream = st;
     c->last_valid = true;
     if (!stats && !single) return T3D_OK;  // asynchronous use: overflow is not checked
@@ -1184,6 +1263,12 @@ extern "C" int t3d_render_rows_device(t3d_ctx* c, const t3d_opts* o, int row0, i
         }
         r += nb;
     }
+    return T3D_OK;
+}
+
+extern "C" int t3d_set_timing(t3d_ctx* c, int per_kernel) {
+    if (!c) return T3D_E_INVALID;
+    c->timing = per_kernel != 0;
     return T3D_OK;
 }
 
