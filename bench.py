@@ -33,7 +33,23 @@ FLOP_PER_SPHERE_TEST = 19.0
 FP32_VALU_PEAK_TFLOPS = 157.3  # 256 CU x 128 FMA lanes x 2 flop x 2.4 GHz
 
 
-def cpu_baseline(flat, options, seed, row_step=4):
+def pmc_traffic(workload):
+    """HBM bytes per k_level launch from the newest committed counter run (profiles/*_pmc_traffic.json, made by
+    tools/gpu_pmc.sh + tools/pmc_summary.py); None when there is none for this workload.  Counters cannot be
+    read from inside this process, so this is the one roofline field that is not measured live."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if d.get("workload") == workload and d.get("kernel") == "k_level":
+            best = (d, os.path.basename(path))
+    return best
+
+
+def cpu_baseline(flat, options, seed, row_step=1):
     """Oracle timed on host threads: every `row_step`-th image row of the same frame, rows dealt
     round-robin to the threads (ctypes releases the GIL during the C call)."""
     from oracle import oracle
@@ -58,7 +74,7 @@ def cpu_baseline(flat, options, seed, row_step=4):
     dt = time.time() - t0
     queries = sum(r["queries"] for r in results if r)
     return {"value": queries / dt / 1e6, "unit": "Mrays/s", "cores": nthreads, "kind": "port",
-            "sample": f"{len(rows)} of {H} rows (every {row_step}th) of the same frame, {queries} queries in {dt:.2f} s",
+            "sample": f"{len(rows)} of {H} rows of the same frame (row step {row_step}), {queries} queries in {dt:.2f} s on {nthreads} threads",
             "seconds": round(dt, 3)}
 
 
@@ -162,6 +178,10 @@ def main():
                          "queries_per_launch": last["queries"] / max(1, last["n_k_level"]),
                          "frame_device_ms": round(last["ms_device"], 4), "resolve_ms": round(last["ms_resolve"], 4)},
         }
+        tr = pmc_traffic(args.workload) if world == 1 else None
+        if tr:
+            line["roofline"]["traffic"] = tr[0]["hbm_bytes_per_launch"]
+            line["roofline"]["traffic_source"] = "profiles/" + tr[1]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(flat, options, seed)
         print(json.dumps(line), flush=True)

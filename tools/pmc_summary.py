@@ -2,7 +2,7 @@
 """Aggregate a rocprofv3 --pmc counter_collection CSV: mean counter value per kernel (per dispatch)."""
 import csv, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for path in sys.argv[1:]:
+for path in [a for a in sys.argv[1:] if a.endswith(".csv")]:
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"].replace("void ", "").split("(")[0]
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -12,3 +12,18 @@ for k, cs in acc.items():
     print(k)
     for c, v in sorted(cs.items()):
         print(f"    {c:28s} n={len(v):4d} mean={sum(v)/len(v):16.1f}")
+
+# --traffic-json PATH: HBM bytes per k_level launch from the FETCH_SIZE / WRITE_SIZE passes.
+# Both counters are in KiB; on gfx950 FETCH_SIZE tallies wide (16 B per lane) reads at half their size,
+# which is the access pattern of the ray / node records, so the read side is doubled.
+if "--traffic-json" in sys.argv:
+    import json
+    out = sys.argv[sys.argv.index("--traffic-json") + 1]
+    f = [x for k, cs in acc.items() if k.startswith("k_level") for x in cs.get("FETCH_SIZE", [])]
+    w = [x for k, cs in acc.items() if k.startswith("k_level") for x in cs.get("WRITE_SIZE", [])]
+    if f and w:
+        fk, wk = sum(f) / len(f), sum(w) / len(w)
+        json.dump({"kernel": "k_level", "workload": "cornell_1080p_b4", "fetch_size_kib_per_launch": round(fk, 1),
+                   "write_size_kib_per_launch": round(wk, 1), "fetch_correction": 2.0,
+                   "hbm_bytes_per_launch": int((2.0 * fk + wk) * 1024), "launches_sampled": [len(f), len(w)]},
+                  open(out, "w"), indent=1)
