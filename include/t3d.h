@@ -200,6 +200,19 @@ int t3d_last_call_stats(t3d_ctx* ctx, t3d_stats* stats);
  */
 int t3d_set_timing(t3d_ctx* ctx, int per_kernel);
 
+/*
+ * Acceleration structure used by scenes uploaded AFTER this call.
+ *   T3D_ACCEL_AUTO         brute force over plane groups up to T3D_BRUTE_FORCE_MAX_PRIMS triangles + spheres,
+ *                          the LBVH above (default)
+ *   T3D_ACCEL_BRUTE_FORCE  always the brute-force loop
+ *   T3D_ACCEL_LBVH         always the device-built LBVH (needs at least two primitives)
+ * Stands where the reference has options['bvh'] / options['aabb'] (T3DR.py:659-707): there, as here, the
+ * hierarchy is a conservative cull and the hit found is the brute-force closest hit.
+ */
+enum { T3D_ACCEL_AUTO = 0, T3D_ACCEL_BRUTE_FORCE = 1, T3D_ACCEL_LBVH = 2 };
+#define T3D_BRUTE_FORCE_MAX_PRIMS 256
+int t3d_set_accel(t3d_ctx* ctx, int mode);
+
 int t3d_abi_version(void);
 
 #ifdef __cplusplus

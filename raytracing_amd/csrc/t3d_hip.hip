@@ -93,10 +93,16 @@ struct DevGeo {
     int axis_end[3];  // plane groups [0, axis_end[0]) have their largest normal component along x, then y, then z
     int n_tris, n_spheres;
 };
+struct DevBvh {
+    const float4* nodes;   // [n_prims - 1] x 4 rows, see t3d_lbvh.h; null when the scene is traced by brute force
+    const float4* tri_ab;  // [2T] per triangle (a.xyz, aw), (b.xyz, bw): u = a.P + aw, v = b.P + bw
+    int n_prims;
+};
 struct DevScene {
     DevGeo geo;
+    DevBvh bvh;
     int n_planes, n_tris, n_spheres, n_lights, n_shaders;
-    const float4* tri_n;       // [T]: the triangle's own un-normalised normal (w unused)
+    const float4* tri_n;       // [T]: the triangle's own un-normalised normal, w = -(n . v0)
     const int4* tri_meta;      // [T]: (object, face-in-mesh, shader, unused); triangles in plane-group order
     const DevLight* lights;    // [L]
     const DevShader* shaders;  // [K]
@@ -135,6 +141,8 @@ struct NodePool {
     float* li;  // [levels * cap * L] direct-light intensity per (node, light), written by k_level
 };
 
+#include "t3d_lbvh.h"
+
 // Queue counters.  Same-address device-scope atomics retire at roughly one per 7 ns on this chip, so one
 // counter per level would serialise the kernel: every level has T3D_SHARDS counters, each in its own
 // 64-byte line, and wave w only ever touches shard w % T3D_SHARDS.
@@ -147,6 +155,9 @@ struct Counters {
     PaddedCount n_nodes[T3D_MAX_BOUNCES + 2][T3D_SHARDS];  // shaded nodes of each level, per shard
     int overflow;
     int n_dbg;
+    int bvh_stack_overflow;
+    int pad_[13];
+    unsigned long long bvh_stat[T3D_SHARDS][8];  // per shard: nodes visited, triangle tests, sphere tests (one 64-byte line each)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -292,8 +303,10 @@ __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0
         if (sp.is_light && !lights) continue;  // wave-uniform
         const f2 Lx = ox - splat(sp.cx), Ly = oy - splat(sp.cy), Lz = oz - splat(sp.cz);
         const f2 b = fma2(Lz, dz, fma2(Ly, dy, Lx * dx));
-        const f2 cc = fma2(Lz, Lz, fma2(Ly, Ly, Lx * Lx)) - splat(sp.r2);
-        const f2 disc = fma2(b, b, -cc);
+        // b^2 - (L.L - r^2) evaluated as r^2 - |L - b d|^2 (d is a unit vector): the textbook form cancels to
+        // a few digits in float32 once the sphere is many radii away
+        const f2 qx = fma2(-b, dx, Lx), qy = fma2(-b, dy, Ly), qz = fma2(-b, dz, Lz);
+        const f2 disc = splat(sp.r2) - fma2(qz, qz, fma2(qy, qy, qx * qx));
         const f2 root = {__builtin_amdgcn_sqrtf(fmaxf(disc.x, 0.0f)), __builtin_amdgcn_sqrtf(fmaxf(disc.y, 0.0f))};
         const f2 t1 = -b - root, t2 = -b + root;
         {
@@ -315,6 +328,107 @@ __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0
     }
     out0.t = __uint_as_float(best0); out0.prim = prim0; out0.back = back0;
     out1.t = __uint_as_float(best1); out1.prim = prim1; out1.back = back1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// closest hit through the LBVH (t3d_lbvh.h): one ray per lane, near child first, stack in private memory.
+// Same acceptance rules as the brute-force loop; equal distances go to the primitive that comes first in
+// the scene's object / face order, whatever order the traversal meets them in.
+// ------------------------------------------------------------------------------------------------
+#define T3D_BVH_STACK 64
+struct BvhCount {
+    uint32_t nodes, tris, spheres;
+};
+
+__device__ __forceinline__ void bvh_closest(const DevScene& sc, const DevSphere* __restrict__ spheres, V3 o, V3 d, bool active,
+                                            bool lights, bool back_cull, Hit& out, BvhCount& bc, int* stack_overflow) {
+    out.t = __builtin_inff(); out.prim = -1; out.back = 0;
+    if (!active) return;
+    const float4* __restrict__ nodes = sc.bvh.nodes;
+    const float4* __restrict__ tri_ab = sc.bvh.tri_ab;
+    const int n_tris = sc.n_tris;
+    // 1/d with zero components replaced by a huge finite value: 0 * inf would be NaN on a box face
+    const float BIGF = 1e30f;
+    const V3 inv = mk(fminf(fmaxf(__builtin_amdgcn_rcpf(d.x), -BIGF), BIGF), fminf(fmaxf(__builtin_amdgcn_rcpf(d.y), -BIGF), BIGF),
+                      fminf(fmaxf(__builtin_amdgcn_rcpf(d.z), -BIGF), BIGF));
+    const V3 oi = mk(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+    float best = __builtin_inff();
+    int prim = -1, back = 0, rank = 0x7fffffff;
+    int stack[T3D_BVH_STACK];
+    int sp = 0;
+    int node = 0;
+    for (;;) {
+        if (node >= 0) {
+            const float4 r0 = nodes[4 * (size_t)node + 0], r1 = nodes[4 * (size_t)node + 1];
+            const float4 r2 = nodes[4 * (size_t)node + 2], r3 = nodes[4 * (size_t)node + 3];
+            bc.nodes++;
+            // slabs: t = (plane - o) / d = plane * inv + oi
+            const float ax0 = fmaf(r0.x, inv.x, oi.x), bx0 = fmaf(r0.w, inv.x, oi.x);
+            const float ay0 = fmaf(r0.y, inv.y, oi.y), by0 = fmaf(r1.x, inv.y, oi.y);
+            const float az0 = fmaf(r0.z, inv.z, oi.z), bz0 = fmaf(r1.y, inv.z, oi.z);
+            const float ax1 = fmaf(r1.z, inv.x, oi.x), bx1 = fmaf(r2.y, inv.x, oi.x);
+            const float ay1 = fmaf(r1.w, inv.y, oi.y), by1 = fmaf(r2.z, inv.y, oi.y);
+            const float az1 = fmaf(r2.x, inv.z, oi.z), bz1 = fmaf(r2.w, inv.z, oi.z);
+            const float n0 = fmaxf(fmaxf(fminf(ax0, bx0), fminf(ay0, by0)), fmaxf(fminf(az0, bz0), 0.0f));
+            const float f0 = fminf(fminf(fmaxf(ax0, bx0), fmaxf(ay0, by0)), fminf(fmaxf(az0, bz0), best)) * 1.0000004f;
+            const float n1 = fmaxf(fmaxf(fminf(ax1, bx1), fminf(ay1, by1)), fmaxf(fminf(az1, bz1), 0.0f));
+            const float f1 = fminf(fminf(fmaxf(ax1, bx1), fmaxf(ay1, by1)), fminf(fmaxf(az1, bz1), best)) * 1.0000004f;
+            const bool h0 = n0 <= f0, h1 = n1 <= f1;
+            const int c0 = __float_as_int(r3.x), c1 = __float_as_int(r3.y);
+            if (h0 & h1) {
+                const bool first0 = n0 <= n1;
+                if (sp < T3D_BVH_STACK) stack[sp++] = first0 ? c1 : c0; else *stack_overflow = 1;
+                node = first0 ? c0 : c1;
+                continue;
+            }
+            if (h0 | h1) { node = h0 ? c0 : c1; continue; }
+        } else {
+            const int p = ~node;
+            if (p < n_tris) {
+                // getFaceCollision (T3DR.py:624-651) for one triangle
+                bc.tris++;
+                const float4 rn = sc.tri_n[p];
+                const float dn = fmaf(rn.z, d.z, fmaf(rn.y, d.y, rn.x * d.x));
+                if (fabsf(dn) >= 1e-6f && (!back_cull || dn < 0.0f)) {
+                    const float q = fmaf(rn.z, o.z, fmaf(rn.y, o.y, fmaf(rn.x, o.x, rn.w)));
+                    const float t = -q * __builtin_amdgcn_rcpf(dn);
+                    if (t >= 0.0f && t <= best) {
+                        const V3 P = madd(o, d, t);
+                        const float4 ra = tri_ab[2 * (size_t)p], rb = tri_ab[2 * (size_t)p + 1];
+                        const float u = fmaf(ra.z, P.z, fmaf(ra.y, P.y, fmaf(ra.x, P.x, ra.w)));
+                        const float v = fmaf(rb.z, P.z, fmaf(rb.y, P.y, fmaf(rb.x, P.x, rb.w)));
+                        const float w = (1.0f - u) - v;
+                        if (fminf(fminf(u, v), w) > 0.0f) {
+                            const int rk = sc.tri_meta[p].w;  // index in the scene's object / face order
+                            if (t < best || rk < rank) { best = t; prim = p; rank = rk; back = 0; }
+                        }
+                    }
+                }
+            } else {
+                // getSphereCollision (T3DR.py:572-598)
+                const DevSphere s = spheres[p - n_tris];
+                if (!s.is_light || lights) {
+                    bc.spheres++;
+                    const V3 Lv = mk(o.x - s.cx, o.y - s.cy, o.z - s.cz);
+                    const float b = dot(Lv, d);
+                    const V3 qv = madd(Lv, d, -b);  // L - b d: see closest_hit2
+                    const float disc = s.r2 - dot(qv, qv);
+                    if (disc >= 0.0f) {
+                        const float root = __builtin_amdgcn_sqrtf(disc);
+                        const float t1 = -b - root, t2 = -b + root;
+                        const bool front = t1 > 0.0f;
+                        const bool inside = (!front) & (t2 > 0.0f) & (!back_cull) & (s.is_light == 0);
+                        const float t = front ? t1 : t2;
+                        const int rk = 0x40000000 + (p - n_tris);  // spheres after all triangles on equal distance
+                        if ((front | inside) && (t < best || (t == best && rk < rank))) { best = t; prim = p; rank = rk; back = front ? 0 : 1; }
+                    }
+                }
+            }
+        }
+        if (sp == 0) break;
+        node = stack[--sp];
+    }
+    out.t = best; out.prim = prim; out.back = back;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -626,7 +740,7 @@ __device__ __forceinline__ void load_ray(const DevScene& sc, const RenderParams&
 // 64-byte line, own slice of the arrays) with wave64 ballot + prefix-popcount compaction and ONE atomic
 // per counter per 64 rays.
 // ------------------------------------------------------------------------------------------------
-template <bool LEVEL0>
+template <bool LEVEL0, bool BVH>
 __global__ __launch_bounds__(T3D_BLOCK) void k_level(DevScene sc, GEO_PARAMS, RenderParams rp, int level,
                                                      const RayRec* __restrict__ rays_in, RayRec* __restrict__ rays_out,
                                                      NodePool pool, Counters* cnt, TraceOut out) {
@@ -652,6 +766,7 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_level(DevScene sc, GEO_PARAMS, Re
     const int chunk_step = LEVEL0 ? nw : nw / T3D_SHARDS;
     int ring_nodes = 0;  // nodes appended to the ring so far      (wave-uniform)
     int items_done = 0;  // (node, light) pairs already traced     (wave-uniform)
+    BvhCount bc{0, 0, 0};
     for (;;) {
         const int pending = ring_nodes * L - items_done;
         const bool more = (long long)chunk * 128 < n_in;
@@ -666,7 +781,12 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_level(DevScene sc, GEO_PARAMS, Re
             const ShadowRay s0 = shadow_ray(sc, ring_a[nd0 % T3D_RING], rb0, l0);
             const ShadowRay s1 = shadow_ray(sc, ring_a[nd1 % T3D_RING], rb1, l1);
             Hit h0, h1;
-            closest_hit2(GEO_ARGS, sc.geo, s0.start, s0.Ld, s1.start, s1.Ld, true, false, false, h0, h1);
+            if constexpr (BVH) {
+                bvh_closest(sc, spheres, s0.start, s0.Ld, run0, true, false, h0, bc, &cnt->bvh_stack_overflow);
+                bvh_closest(sc, spheres, s1.start, s1.Ld, run1, true, false, h1, bc, &cnt->bvh_stack_overflow);
+            } else {
+                closest_hit2(GEO_ARGS, sc.geo, s0.start, s0.Ld, s1.start, s1.Ld, true, false, false, h0, h1);
+            }
             const float I0 = shadow_intensity(sc, spheres, s0, h0), I1 = shadow_intensity(sc, spheres, s1, h1);
             if (run0) pool.li[(wc.node_base + (size_t)__float_as_int(rb0.w)) * L + l0] = I0;
             if (run1) pool.li[(wc.node_base + (size_t)__float_as_int(rb1.w)) * L + l1] = I1;
@@ -677,9 +797,13 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_level(DevScene sc, GEO_PARAMS, Re
             load_ray<LEVEL0>(sc, rp, rays_in, chunk * 128 + wc.lane, n_in, queue_base, in0);
             load_ray<LEVEL0>(sc, rp, rays_in, chunk * 128 + 64 + wc.lane, n_in, queue_base, in1);
             const bool lights = LEVEL0 ? (rp.lights != 0) : true;
-            Hit h0, h1;
-            closest_hit2(GEO_ARGS, sc.geo, in0.o, in0.d, in1.o, in1.d, lights,
-                         in0.ior == 1.0f, in1.ior == 1.0f, h0, h1);  // back faces culled iff ray.ior == 1 (T3DR.py:961)
+            Hit h0, h1;  // back faces culled iff ray.ior == 1 (T3DR.py:961)
+            if constexpr (BVH) {
+                bvh_closest(sc, spheres, in0.o, in0.d, in0.active, lights, in0.ior == 1.0f, h0, bc, &cnt->bvh_stack_overflow);
+                bvh_closest(sc, spheres, in1.o, in1.d, in1.active, lights, in1.ior == 1.0f, h1, bc, &cnt->bvh_stack_overflow);
+            } else {
+                closest_hit2(GEO_ARGS, sc.geo, in0.o, in0.d, in1.o, in1.d, lights, in0.ior == 1.0f, in1.ior == 1.0f, h0, h1);
+            }
             process_ray<LEVEL0>(sc, spheres, rp, wc, in0, h0, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes);
             process_ray<LEVEL0>(sc, spheres, rp, wc, in1, h1, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes);
             chunk += chunk_step;
@@ -690,6 +814,18 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_level(DevScene sc, GEO_PARAMS, Re
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         } else {
             break;
+        }
+    }
+    if constexpr (BVH) {
+        // traversal statistics: wave sum, one atomic per counter on the wave's own counter line
+        unsigned long long a = bc.nodes, b = bc.tris, c = bc.spheres;
+        for (int off = 32; off > 0; off >>= 1) {
+            a += __shfl_xor(a, off); b += __shfl_xor(b, off); c += __shfl_xor(c, off);
+        }
+        if (wc.lane == 0) {
+            atomicAdd(&cnt->bvh_stat[wc.shard][0], a);
+            atomicAdd(&cnt->bvh_stat[wc.shard][1], b);
+            atomicAdd(&cnt->bvh_stat[wc.shard][2], c);
         }
     }
 }
@@ -772,7 +908,13 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_closest(DevScene sc, GEO_PARAMS, 
     V3 o = mk(origins[3 * j], origins[3 * j + 1], origins[3 * j + 2]);
     V3 d = normalize(mk(dirs[3 * j], dirs[3 * j + 1], dirs[3 * j + 2]));
     Hit h, h_dup;
-    closest_hit2(GEO_ARGS, sc.geo, o, d, o, d, lights != 0, back_cull != 0, back_cull != 0, h, h_dup);
+    if (sc.bvh.nodes) {  // uniform over the launch
+        BvhCount bc{0, 0, 0};
+        int overflow = 0;
+        bvh_closest(sc, spheres, o, d, active, lights != 0, back_cull != 0, h, bc, &overflow);
+    } else {
+        closest_hit2(GEO_ARGS, sc.geo, o, d, o, d, lights != 0, back_cull != 0, back_cull != 0, h, h_dup);
+    }
     if (!active) return;
     int obj = -1, face = -1, dirflag = 0;
     V3 N = mk(0, 0, 0);
@@ -807,6 +949,9 @@ struct t3d_ctx {
     // scene buffers
     DevScene sc{};
     void* d_planes = nullptr; void* d_plane_first = nullptr; void* d_tri_uv = nullptr; void* d_tri_n = nullptr;
+    void* d_bvh_nodes = nullptr; void* d_tri_ab = nullptr;
+    int accel = T3D_ACCEL_AUTO;   // t3d_set_accel
+    bool use_bvh = false;         // the uploaded scene is traced through the LBVH
     void* d_tri_meta = nullptr; void* d_spheres = nullptr; void* d_lights = nullptr;
     void* d_shaders = nullptr; void* d_obj_ior = nullptr;
     int n_objects = 0, n_sphere_objs = 0, n_light_objs = 0;
@@ -879,6 +1024,7 @@ extern "C" int t3d_create(int device, t3d_ctx** out) {
 
 static void free_scene(t3d_ctx* c) {
     hipFree(c->d_planes); hipFree(c->d_plane_first); hipFree(c->d_tri_uv); hipFree(c->d_tri_n);
+    hipFree(c->d_bvh_nodes); hipFree(c->d_tri_ab); c->d_bvh_nodes = c->d_tri_ab = nullptr; c->use_bvh = false;
     hipFree(c->d_tri_meta); hipFree(c->d_spheres); hipFree(c->d_lights);
     hipFree(c->d_shaders); hipFree(c->d_obj_ior);
     c->d_planes = c->d_plane_first = c->d_tri_uv = c->d_tri_n = nullptr;
@@ -1000,6 +1146,7 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
     std::vector<float4> tri_uv((size_t)2 * (s->n_tris + 1), make_float4(0.f, 0.f, 0.f, 0.f));
     std::vector<float4> tri_n((size_t)s->n_tris + 1, make_float4(0.f, 0.f, 0.f, 0.f));
     std::vector<int4> meta((size_t)s->n_tris + 1, make_int4(0, 0, 0, 0));
+    std::vector<int> order((size_t)s->n_tris + 1, 0);  // device position -> index in the description
     {
         int k = 0;
         for (size_t g = 0; g < G; ++g) {
@@ -1023,7 +1170,8 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
                     tri_uv[2 * (size_t)k + 0] = make_float4((float)as, (float)aw + 0.0f, (float)at, 0.f);
                     tri_uv[2 * (size_t)k + 1] = make_float4((float)bs, (float)bw + 0.0f, (float)bt, 0.f);
                 }   // else: degenerate triangle, rows stay zero and min3(u, v, w) = 0 never counts as inside
-                tri_n[k] = make_float4((float)T.n[0], (float)T.n[1], (float)T.n[2], 0.f);
+                tri_n[k] = make_float4((float)T.n[0], (float)T.n[1], (float)T.n[2], -(float)T.nv0 + 0.0f);
+                order[k] = t;
                 meta[k] = make_int4(T.obj, T.face, T.shader, t);
                 ++k;
             }
@@ -1046,7 +1194,36 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
         (rc = upload(c, &c->d_tri_n, tri_n)) || (rc = upload(c, &c->d_tri_meta, meta)) || (rc = upload(c, &c->d_spheres, spheres)) ||
         (rc = upload(c, &c->d_lights, lights)) || (rc = upload(c, &c->d_shaders, shaders)) || (rc = upload(c, &c->d_obj_ior, obj_ior)))
         return rc;
+    // Large scenes are traced through an LBVH over all triangles and spheres, built on the device.
+    const int n_prims = s->n_tris + (int)spheres.size();
+    const bool want_bvh = n_prims >= 2 && (c->accel == T3D_ACCEL_LBVH || (c->accel == T3D_ACCEL_AUTO && n_prims > T3D_BRUTE_FORCE_MAX_PRIMS));
+    if (want_bvh) {
+        // 3-D barycentric rows  a = (e2 x n) / |n|^2, b = (n x e1) / |n|^2 :  P - v0 = u e1 + v e2  (float64, rounded once)
+        std::vector<float4> tri_ab((size_t)2 * (s->n_tris + 1), make_float4(0.f, 0.f, 0.f, 0.f));
+        std::vector<float> verts((size_t)9 * (s->n_tris + 1), 0.f);
+        for (int k = 0; k < s->n_tris; ++k) {
+            const double* v = s->tri_verts + 9 * (size_t)order[k];
+            for (int q = 0; q < 9; ++q) verts[9 * (size_t)k + q] = (float)v[q];
+            const double e1[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]}, e2[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]};
+            const double nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
+            const double nn = nx * nx + ny * ny + nz * nz;
+            if (!(nn > 0)) continue;  // degenerate: rows stay zero, min3(u, v, w) = 0 is never inside
+            const double a[3] = {(e2[1] * nz - e2[2] * ny) / nn, (e2[2] * nx - e2[0] * nz) / nn, (e2[0] * ny - e2[1] * nx) / nn};
+            const double b[3] = {(ny * e1[2] - nz * e1[1]) / nn, (nz * e1[0] - nx * e1[2]) / nn, (nx * e1[1] - ny * e1[0]) / nn};
+            tri_ab[2 * (size_t)k + 0] = make_float4((float)a[0], (float)a[1], (float)a[2], -(float)(a[0] * v[0] + a[1] * v[1] + a[2] * v[2]) + 0.0f);
+            tri_ab[2 * (size_t)k + 1] = make_float4((float)b[0], (float)b[1], (float)b[2], -(float)(b[0] * v[0] + b[1] * v[1] + b[2] * v[2]) + 0.0f);
+        }
+        void* d_verts = nullptr;
+        if ((rc = upload(c, &c->d_tri_ab, tri_ab)) || (rc = upload(c, &d_verts, verts))) { hipFree(d_verts); return rc; }
+        float4* nodes = nullptr;
+        hipError_t e = lbvh_build(c->stream, (const float*)d_verts, s->n_tris, (const DevSphere*)c->d_spheres, (int)spheres.size(), &nodes);
+        hipFree(d_verts);
+        if (e != hipSuccess) { c->err = std::string("t3d_upload_scene: LBVH build failed: ") + hipGetErrorString(e); return T3D_E_DEVICE; }
+        c->d_bvh_nodes = nodes;
+        c->use_bvh = true;
+    }
     DevScene& d = c->sc;
+    d.bvh.nodes = (const float4*)c->d_bvh_nodes; d.bvh.tri_ab = (const float4*)c->d_tri_ab; d.bvh.n_prims = n_prims;
     d.geo.axis_end[0] = axis_count[0]; d.geo.axis_end[1] = axis_count[0] + axis_count[1]; d.geo.axis_end[2] = (int)G;
     d.geo.n_tris = s->n_tris; d.geo.n_spheres = (int)spheres.size();
     d.n_planes = (int)G; d.n_tris = s->n_tris; d.n_spheres = (int)spheres.size(); d.n_lights = s->n_lights; d.n_shaders = s->n_shaders;
@@ -1133,8 +1310,16 @@ static void fill_stats(t3d_ctx* c, t3d_stats* stats) {
     stats->queries += q;
     stats->trace_queries += rays;
     stats->shadow_queries += shadow;
-    stats->tri_tests += q * (uint64_t)c->sc.n_tris;
-    stats->sphere_tests += q * (uint64_t)c->sc.n_spheres - (c->last_lights ? 0 : c->last_n0 * (uint64_t)c->n_light_objs);
+    if (c->use_bvh) {
+        uint64_t nv = 0, tt = 0, stt = 0;
+        for (int sh = 0; sh < T3D_SHARDS; ++sh) { nv += c->h_cnt->bvh_stat[sh][0]; tt += c->h_cnt->bvh_stat[sh][1]; stt += c->h_cnt->bvh_stat[sh][2]; }
+        stats->aabb_tests += 2 * nv;  // every node visited holds the boxes of its two children
+        stats->tri_tests += tt;
+        stats->sphere_tests += stt;
+    } else {
+        stats->tri_tests += q * (uint64_t)c->sc.n_tris;
+        stats->sphere_tests += q * (uint64_t)c->sc.n_spheres - (c->last_lights ? 0 : c->last_n0 * (uint64_t)c->n_light_objs);
+    }
     stats->nodes += nodes;  // shaded nodes only; emitter leaves are folded into their parents
     stats->launches += c->last_launches;
     stats->n_k_level += (uint64_t)levels;
@@ -1184,14 +1369,18 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
     const int* pfirst = (const int*)c->d_plane_first;
     const float4* uv = (const float4*)c->d_tri_uv;
     const DevSphere* sph = (const DevSphere*)c->d_spheres;
+    auto kl0 = c->use_bvh ? k_level<true, true> : k_level<true, false>;
+    auto kln = c->use_bvh ? k_level<false, true> : k_level<false, false>;
     HIPCHK(c, tick());  // ev[0]: start of the call
     for (int d = 0; d < levels; ++d) {
         RayRec* in = c->d_rays[d & 1];
         RayRec* outq = c->d_rays[(d + 1) & 1];
         if (d == 0)
-            hipLaunchKernelGGL(k_level<true>, dim3(trace_blocks_for(n0)), dim3(T3D_BLOCK), 0, st, c->sc, planes, pfirst, uv, sph, rp, d, in, outq, c->pool, c->d_cnt, out);
+            hipLaunchKernelGGL(kl0, dim3(trace_blocks_for(n0)), dim3(T3D_BLOCK), 0, st, c->sc, planes,
+                               pfirst, uv, sph, rp, d, in, outq, c->pool, c->d_cnt, out);
         else
-            hipLaunchKernelGGL(k_level<false>, dim3(single ? (int)grid_unit : trace_blocks_for(c->cap_alloc)), dim3(T3D_BLOCK), 0, st, c->sc, planes, pfirst, uv, sph, rp, d, in, outq, c->pool, c->d_cnt, out);
+            hipLaunchKernelGGL(kln, dim3(single ? (int)grid_unit : trace_blocks_for(c->cap_alloc)),
+                               dim3(T3D_BLOCK), 0, st, c->sc, planes, pfirst, uv, sph, rp, d, in, outq, c->pool, c->d_cnt, out);
         if (c->timing) HIPCHK(c, tick());  // ev[1 + d]: k_level(d) done
         launches += 1;
     }
@@ -1213,6 +1402,7 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
     if (!stats && !single) return T3D_OK;  // asynchronous use: overflow is not checked
     HIPCHK(c, hipStreamSynchronize(st));
     if (c->h_cnt->overflow) return T3D_E_CAPACITY;
+    if (c->h_cnt->bvh_stack_overflow) { c->err = "LBVH traversal stack overflow"; return T3D_E_DEVICE; }
     if (stats) fill_stats(c, stats);
     return T3D_OK;
 }
@@ -1263,6 +1453,13 @@ extern "C" int t3d_render_rows_device(t3d_ctx* c, const t3d_opts* o, int row0, i
         }
         r += nb;
     }
+    return T3D_OK;
+}
+
+extern "C" int t3d_set_accel(t3d_ctx* c, int mode) {
+    if (!c) return T3D_E_INVALID;
+    if (mode != T3D_ACCEL_AUTO && mode != T3D_ACCEL_BRUTE_FORCE && mode != T3D_ACCEL_LBVH) { c->err = "t3d_set_accel: unknown mode"; return T3D_E_INVALID; }
+    c->accel = mode;
     return T3D_OK;
 }
 

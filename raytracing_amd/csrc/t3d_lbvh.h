@@ -1,0 +1,289 @@
+// t3d_lbvh.h -- linear bounding-volume hierarchy built on the GPU (Morton codes, radix sort, Karras'
+// hierarchy, bottom-up refit) over the triangles and spheres of a scene, for scenes too large for the
+// brute-force plane-group loop.
+//
+// The reference culls with a per-mesh median-split BVH of padded boxes (Object.buildBVH T3DE.py:985-1022,
+// Photon.getFaces T3DR.py:553-569, Ray.entersAABB T3DE.py:166-204).  That cull is purely conservative: the
+// closest hit it returns is the brute-force closest hit.  This hierarchy keeps the same contract (boxes are
+// padded outward, a node is entered whenever its slab interval reaches the current best distance) and is
+// otherwise free to differ: one tree over the whole scene, built from Morton order.
+//
+// Included by t3d_hip.hip (one translation unit, one shared library).
+#pragma once
+
+#define LBVH_BLOCK 256
+
+// 64-byte traversal node: the boxes of BOTH children and their links, so one fetch decides two subtrees.
+//   r0 = (lo0.x, lo0.y, lo0.z, hi0.x)  r1 = (hi0.y, hi0.z, lo1.x, lo1.y)
+//   r2 = (lo1.z, hi1.x, hi1.y, hi1.z)  r3 = (child0, child1, 0, 0) as int bits
+// child >= 0: internal node index; child < 0: leaf holding primitive ~child
+// (primitive p < n_tris: triangle p in device order; otherwise sphere p - n_tris).
+struct LbvhWork {
+    float4* prim_lo = nullptr;   // [N] box of primitive p (w unused)
+    float4* prim_hi = nullptr;
+    uint32_t* keys[2] = {nullptr, nullptr};
+    int* vals[2] = {nullptr, nullptr};
+    int* hist = nullptr;
+    int* parent = nullptr;       // [2N-1]: internal nodes 0..N-2, leaves N-1..2N-2 (sorted position + N-1)
+    int2* kids = nullptr;        // [N-1]
+    float4* box_lo = nullptr;    // [N-1] boxes of internal nodes
+    float4* box_hi = nullptr;
+    int* flags = nullptr;        // [N-1] arrival counters of the refit
+    int* bounds = nullptr;       // [6] scene bounds as order-preserving ints
+    void release() {
+        hipFree(prim_lo); hipFree(prim_hi); hipFree(keys[0]); hipFree(keys[1]); hipFree(vals[0]); hipFree(vals[1]);
+        hipFree(hist); hipFree(parent); hipFree(kids); hipFree(box_lo); hipFree(box_hi); hipFree(flags); hipFree(bounds);
+        *this = LbvhWork();
+    }
+};
+
+// float <-> int that keeps the order (for atomicMin / atomicMax on floats)
+__device__ __forceinline__ int lbvh_f2o(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
+__device__ __forceinline__ float lbvh_o2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+// Primitive boxes, padded outward so that float32 rounding of a hit point can never leave the box of the
+// primitive it lies on, and the scene bounds.
+__global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_bounds(const float* __restrict__ verts, int n_tris, const DevSphere* __restrict__ spheres,
+                                                            int n_spheres, float4* __restrict__ prim_lo, float4* __restrict__ prim_hi,
+                                                            int* __restrict__ bounds) {
+    const int n = n_tris + n_spheres;
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+        float blo[3], bhi[3];
+        if (p < n_tris) {
+            const float* v = verts + 9 * (size_t)p;
+            for (int a = 0; a < 3; ++a) {
+                blo[a] = fminf(fminf(v[a], v[3 + a]), v[6 + a]);
+                bhi[a] = fmaxf(fmaxf(v[a], v[3 + a]), v[6 + a]);
+            }
+        } else {
+            const DevSphere sp = spheres[p - n_tris];
+            const float r = __builtin_sqrtf(sp.r2) * 1.000001f;
+            blo[0] = sp.cx - r; blo[1] = sp.cy - r; blo[2] = sp.cz - r;
+            bhi[0] = sp.cx + r; bhi[1] = sp.cy + r; bhi[2] = sp.cz + r;
+        }
+        float ext = 0.0f;
+        for (int a = 0; a < 3; ++a) ext = fmaxf(ext, fmaxf(fmaxf(fabsf(blo[a]), fabsf(bhi[a])), bhi[a] - blo[a]));
+        const float pad = 4e-6f * ext + 1e-30f;
+        for (int a = 0; a < 3; ++a) {
+            blo[a] -= pad; bhi[a] += pad;
+            lo[a] = fminf(lo[a], blo[a]); hi[a] = fmaxf(hi[a], bhi[a]);
+        }
+        prim_lo[p] = make_float4(blo[0], blo[1], blo[2], 0.f);
+        prim_hi[p] = make_float4(bhi[0], bhi[1], bhi[2], 0.f);
+    }
+    // wave reduction, then one atomic per wave and bound
+    for (int a = 0; a < 3; ++a) {
+        float l = lo[a], h = hi[a];
+        for (int off = 32; off > 0; off >>= 1) {
+            l = fminf(l, __shfl_xor(l, off));
+            h = fmaxf(h, __shfl_xor(h, off));
+        }
+        if ((threadIdx.x & 63) == 0 && l <= h) {
+            atomicMin(&bounds[a], lbvh_f2o(l));
+            atomicMax(&bounds[3 + a], lbvh_f2o(h));
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t lbvh_spread10(uint32_t v) {  // 10 bits -> every third bit
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+// 30-bit Morton code of the box centre inside the scene bounds.
+__global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_morton(const float4* __restrict__ prim_lo, const float4* __restrict__ prim_hi, int n,
+                                                            const int* __restrict__ bounds, uint32_t* __restrict__ keys, int* __restrict__ vals) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const float4 lo = prim_lo[p], hi = prim_hi[p];
+    const float c[3] = {0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)};
+    uint32_t q[3];
+    for (int a = 0; a < 3; ++a) {
+        const float l = lbvh_o2f(bounds[a]), h = lbvh_o2f(bounds[3 + a]);
+        const float ext = h - l;
+        float x = ext > 0.0f ? (c[a] - l) / ext : 0.0f;
+        x = fminf(fmaxf(x * 1024.0f, 0.0f), 1023.0f);
+        q[a] = (uint32_t)x;
+    }
+    keys[p] = (lbvh_spread10(q[0]) << 2) | (lbvh_spread10(q[1]) << 1) | lbvh_spread10(q[2]);
+    vals[p] = p;
+}
+
+// Stable LSD radix sort, 8 bits per pass.  Thread t owns the contiguous chunk [t*chunk, (t+1)*chunk): it
+// counts its digits into hist[digit * nt + t], a scan over the digit-major table gives every (digit, thread)
+// its first output slot, and the thread scatters its chunk in order.  Not a fast sort; the build runs once
+// per scene.
+__global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_rs_count(const uint32_t* __restrict__ keys, int n, int shift, int chunk, int nt,
+                                                              int* __restrict__ hist) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    const int b = t * chunk, e = min(n, b + chunk);
+    for (int i = b; i < e; ++i) hist[((keys[i] >> shift) & 255u) * nt + t] += 1;
+}
+__global__ __launch_bounds__(1024) void k_lbvh_rs_scan(int* __restrict__ hist, int m) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (m + 1023) / 1024;
+    const int b = t * per, e = min(m, b + per);
+    int s = 0;
+    for (int i = b; i < e; ++i) s += hist[i];
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - s;  // exclusive prefix of this thread's range
+    for (int i = b; i < e; ++i) { int v = hist[i]; hist[i] = run; run += v; }
+}
+__global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_rs_scatter(const uint32_t* __restrict__ keys, const int* __restrict__ vals, int n, int shift,
+                                                                int chunk, int nt, int* __restrict__ hist, uint32_t* __restrict__ keys_out,
+                                                                int* __restrict__ vals_out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    const int b = t * chunk, e = min(n, b + chunk);
+    for (int i = b; i < e; ++i) {
+        const uint32_t k = keys[i];
+        const int slot = ((k >> shift) & 255u) * nt + t;
+        const int pos = hist[slot];
+        hist[slot] = pos + 1;
+        keys_out[pos] = k;
+        vals_out[pos] = vals[i];
+    }
+}
+
+// Length of the common prefix of the keys at sorted positions i and j; equal keys are told apart by
+// their positions (Karras 2012), out-of-range j gives -1.
+__device__ __forceinline__ int lbvh_delta(const uint32_t* __restrict__ keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    const uint32_t a = keys[i], b = keys[j];
+    return a != b ? __clz(a ^ b) : 32 + __clz((uint32_t)i ^ (uint32_t)j);
+}
+
+// One thread per internal node: its key range, split position and children.
+__global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_hierarchy(const uint32_t* __restrict__ keys, int n, int2* __restrict__ kids,
+                                                               int* __restrict__ parent) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = lbvh_delta(keys, n, i, i + 1) - lbvh_delta(keys, n, i, i - 1) >= 0 ? 1 : -1;
+    const int dmin = lbvh_delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (lbvh_delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (lbvh_delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = lbvh_delta(keys, n, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (lbvh_delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + min(d, 0);
+    const int lo = min(i, j), hi = max(i, j);
+    // node ids: internal g -> g, leaf at sorted position g -> (n - 1) + g
+    const int left = lo == gamma ? (n - 1) + gamma : gamma;
+    const int right = hi == gamma + 1 ? (n - 1) + gamma + 1 : gamma + 1;
+    kids[i] = make_int2(left, right);
+    parent[left] = i;
+    parent[right] = i;
+    if (i == 0) parent[0] = -1;
+}
+
+// Bottom-up boxes: every leaf climbs; the first thread to reach a node stops, the second one (whose
+// sibling subtree is therefore complete) computes the node's box and goes on.
+__global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_refit(const int* __restrict__ vals, int n, const float4* __restrict__ prim_lo,
+                                                           const float4* __restrict__ prim_hi, const int2* __restrict__ kids,
+                                                           const int* __restrict__ parent, float4* box_lo, float4* box_hi, int* flags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int cur = parent[(n - 1) + i];
+    while (cur >= 0) {
+        // release our subtree's boxes, acquire the sibling's
+        if (__hip_atomic_fetch_add(&flags[cur], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+        const int2 k = kids[cur];
+        float4 l0, h0, l1, h1;
+        if (k.x >= n - 1) { const int p = vals[k.x - (n - 1)]; l0 = prim_lo[p]; h0 = prim_hi[p]; }
+        else { l0 = box_lo[k.x]; h0 = box_hi[k.x]; }
+        if (k.y >= n - 1) { const int p = vals[k.y - (n - 1)]; l1 = prim_lo[p]; h1 = prim_hi[p]; }
+        else { l1 = box_lo[k.y]; h1 = box_hi[k.y]; }
+        box_lo[cur] = make_float4(fminf(l0.x, l1.x), fminf(l0.y, l1.y), fminf(l0.z, l1.z), 0.f);
+        box_hi[cur] = make_float4(fmaxf(h0.x, h1.x), fmaxf(h0.y, h1.y), fmaxf(h0.z, h1.z), 0.f);
+        cur = parent[cur];
+    }
+}
+
+// Traversal nodes: both child boxes and links in one 64-byte record.
+__global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_pack(const int* __restrict__ vals, int n, const float4* __restrict__ prim_lo,
+                                                          const float4* __restrict__ prim_hi, const int2* __restrict__ kids,
+                                                          const float4* __restrict__ box_lo, const float4* __restrict__ box_hi,
+                                                          float4* __restrict__ nodes) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const int2 k = kids[i];
+    float4 l0, h0, l1, h1;
+    int c0, c1;
+    if (k.x >= n - 1) { const int p = vals[k.x - (n - 1)]; l0 = prim_lo[p]; h0 = prim_hi[p]; c0 = ~p; }
+    else { l0 = box_lo[k.x]; h0 = box_hi[k.x]; c0 = k.x; }
+    if (k.y >= n - 1) { const int p = vals[k.y - (n - 1)]; l1 = prim_lo[p]; h1 = prim_hi[p]; c1 = ~p; }
+    else { l1 = box_lo[k.y]; h1 = box_hi[k.y]; c1 = k.y; }
+    nodes[4 * (size_t)i + 0] = make_float4(l0.x, l0.y, l0.z, h0.x);
+    nodes[4 * (size_t)i + 1] = make_float4(h0.y, h0.z, l1.x, l1.y);
+    nodes[4 * (size_t)i + 2] = make_float4(l1.z, h1.x, h1.y, h1.z);
+    nodes[4 * (size_t)i + 3] = make_float4(__int_as_float(c0), __int_as_float(c1), 0.f, 0.f);
+}
+
+// Build the hierarchy over n_tris triangles (vertices in device order, 9 floats each) and n_spheres
+// spheres; *out_nodes receives n - 1 traversal nodes (hipMalloc, owned by the caller).  Needs n >= 2.
+static hipError_t lbvh_build(hipStream_t st, const float* d_verts, int n_tris, const DevSphere* d_spheres, int n_spheres,
+                             float4** out_nodes) {
+    const int n = n_tris + n_spheres;
+    LbvhWork w;
+    hipError_t e = hipSuccess;
+    float4* nodes = nullptr;
+    const int nt = n < 16384 * 16 ? (n + 15) / 16 : 16384;  // sort threads
+    const int chunk = (n + nt - 1) / nt;
+    auto blocks = [](int k) { return dim3((unsigned)((k + LBVH_BLOCK - 1) / LBVH_BLOCK)); };
+#define LB(x) do { e = (x); if (e != hipSuccess) { w.release(); hipFree(nodes); return e; } } while (0)
+    LB(hipMalloc(&w.prim_lo, sizeof(float4) * n)); LB(hipMalloc(&w.prim_hi, sizeof(float4) * n));
+    for (int k = 0; k < 2; ++k) { LB(hipMalloc(&w.keys[k], sizeof(uint32_t) * n)); LB(hipMalloc(&w.vals[k], sizeof(int) * n)); }
+    LB(hipMalloc(&w.hist, sizeof(int) * 256 * (size_t)nt));
+    LB(hipMalloc(&w.parent, sizeof(int) * (2 * (size_t)n - 1))); LB(hipMalloc(&w.kids, sizeof(int2) * (n - 1)));
+    LB(hipMalloc(&w.box_lo, sizeof(float4) * (n - 1))); LB(hipMalloc(&w.box_hi, sizeof(float4) * (n - 1)));
+    LB(hipMalloc(&w.flags, sizeof(int) * (n - 1))); LB(hipMalloc(&w.bounds, sizeof(int) * 6));
+    LB(hipMalloc(&nodes, sizeof(float4) * 4 * (size_t)(n - 1)));
+    const int init_bounds[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+    LB(hipMemcpyAsync(w.bounds, init_bounds, sizeof init_bounds, hipMemcpyHostToDevice, st));
+    LB(hipStreamSynchronize(st));  // init_bounds is a stack array
+    int nb = (n + LBVH_BLOCK - 1) / LBVH_BLOCK;
+    hipLaunchKernelGGL(k_lbvh_bounds, dim3((unsigned)(nb > 1024 ? 1024 : nb)), dim3(LBVH_BLOCK), 0, st, d_verts, n_tris, d_spheres, n_spheres,
+                       w.prim_lo, w.prim_hi, w.bounds);
+    hipLaunchKernelGGL(k_lbvh_morton, blocks(n), dim3(LBVH_BLOCK), 0, st, w.prim_lo, w.prim_hi, n, w.bounds, w.keys[0], w.vals[0]);
+    int cur = 0;
+    for (int shift = 0; shift < 32; shift += 8) {
+        LB(hipMemsetAsync(w.hist, 0, sizeof(int) * 256 * (size_t)nt, st));
+        hipLaunchKernelGGL(k_lbvh_rs_count, blocks(nt), dim3(LBVH_BLOCK), 0, st, w.keys[cur], n, shift, chunk, nt, w.hist);
+        hipLaunchKernelGGL(k_lbvh_rs_scan, dim3(1), dim3(1024), 0, st, w.hist, 256 * nt);
+        hipLaunchKernelGGL(k_lbvh_rs_scatter, blocks(nt), dim3(LBVH_BLOCK), 0, st, w.keys[cur], w.vals[cur], n, shift, chunk, nt, w.hist,
+                           w.keys[cur ^ 1], w.vals[cur ^ 1]);
+        cur ^= 1;
+    }
+    LB(hipMemsetAsync(w.flags, 0, sizeof(int) * (n - 1), st));
+    hipLaunchKernelGGL(k_lbvh_hierarchy, blocks(n - 1), dim3(LBVH_BLOCK), 0, st, w.keys[cur], n, w.kids, w.parent);
+    hipLaunchKernelGGL(k_lbvh_refit, blocks(n), dim3(LBVH_BLOCK), 0, st, w.vals[cur], n, w.prim_lo, w.prim_hi, w.kids, w.parent, w.box_lo,
+                       w.box_hi, w.flags);
+    hipLaunchKernelGGL(k_lbvh_pack, blocks(n - 1), dim3(LBVH_BLOCK), 0, st, w.vals[cur], n, w.prim_lo, w.prim_hi, w.kids, w.box_lo, w.box_hi,
+                       nodes);
+    LB(hipGetLastError());
+    LB(hipStreamSynchronize(st));
+#undef LB
+    w.release();
+    *out_nodes = nodes;
+    return hipSuccess;
+}

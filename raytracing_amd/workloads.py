@@ -69,19 +69,21 @@ def cornell_scene(with_light=True, suzanne=False) -> Scene:
     return scene
 
 
-def synthetic_scene(n_random_tris=500_000, grid=500, n_spheres=10_000, seed=1234) -> Scene:
-    """Large synthetic scene: random small triangles in [-50, 50]^3, a ground grid of 2*grid^2
-    triangles at y = -50, random spheres, 8 shaders, 4 lights, camera at (0, 0, -120)."""
+def synthetic_scene(n_random_tris=500_000, grid=500, n_spheres=10_000, seed=1234, extent=50.0, camera=None) -> Scene:
+    """Large synthetic scene: random small triangles in [-extent, extent]^3, a ground grid of 2*grid^2
+    triangles at y = -extent, random spheres, 8 shaders, 4 lights, camera at (0, 0, -2.4 extent) unless given
+    (with the default camera many pixel rays meet the regular ground grid exactly on its edges)."""
     rng = np.random.default_rng(seed)
     scene = Scene()
-    centres = rng.uniform(-50, 50, (n_random_tris, 3))
+    E = float(extent)
+    centres = rng.uniform(-E, E, (n_random_tris, 3))
     e1 = rng.uniform(-0.5, 0.5, (n_random_tris, 3))
     e2 = rng.uniform(-0.5, 0.5, (n_random_tris, 3))
     tri = np.stack([centres, centres + e1, centres + e2], axis=1)
-    xs = np.linspace(-50, 50, grid + 1)
+    xs = np.linspace(-E, E, grid + 1)
     gx, gz = np.meshgrid(xs[:-1], xs[:-1], indexing="ij")
     step = xs[1] - xs[0]
-    y = np.full(gx.size, -50.0)
+    y = np.full(gx.size, -E)
     p00 = np.stack([gx.ravel(), y, gz.ravel()], 1)
     p10 = p00 + [step, 0, 0]
     p01 = p00 + [0, 0, step]
@@ -98,15 +100,15 @@ def synthetic_scene(n_random_tris=500_000, grid=500, n_spheres=10_000, seed=1234
     for k, sh in enumerate(shaders):
         obj.setShader(sh, np.nonzero(pick == k)[0].tolist())
     obj.material = Material(ior=1.3)
-    sc = rng.uniform(-50, 50, (n_spheres, 3))
+    sc = rng.uniform(-E, E, (n_spheres, 3))
     sr = rng.uniform(0.1, 0.6, n_spheres)
     for i in range(n_spheres):
         s = Sphere(scene=scene, name=f"S{i}", position=Vec3(*map(float, sc[i])))
         s.scale = Scale(float(2 * sr[i]), float(2 * sr[i]), float(2 * sr[i]))
         s.setShader(shaders[i % 8])
     for i, pos in enumerate([(0, 40, -60), (-40, 30, 0), (40, 30, 0), (0, 45, 40)]):
-        Light(scene=scene, name=f"L{i}", position=Vec3(*pos), strength=1.0)
-    _camera(scene, position=(0, 0, -120), length=20)
+        Light(scene=scene, name=f"L{i}", position=Vec3(*(float(q) * E / 50.0 for q in pos)), strength=1.0)
+    _camera(scene, position=camera if camera is not None else (0, 0, -2.4 * E), length=20)
     return scene
 
 
