@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 FLOP_PER_TRI_TEST = 51.0     # Moeller-Trumbore with on-the-fly edges
 FLOP_PER_SPHERE_TEST = 19.0
 FP32_VALU_PEAK_TFLOPS = 157.3  # 256 CU x 128 FMA lanes x 2 flop x 2.4 GHz
+HBM_PEAK_GBS = 8000.0
 
 
 def pmc_traffic(workload):
@@ -56,6 +57,8 @@ def cpu_baseline(flat, options, seed, row_step=1):
     oracle.lib()
     nthreads = max(1, min(16, os.cpu_count() or 1))
     H = options["height"]
+    if row_step <= 0:
+        row_step = max(1, H // nthreads)   # one row per thread
     rows = list(range(0, H, row_step))
     stride = row_step * nthreads
     results = [None] * nthreads
@@ -86,6 +89,7 @@ def main():
     ap.add_argument("--workload", default="cornell_1080p_b4")
     ap.add_argument("--partition", default="interleaved", choices=["interleaved", "bands"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-row-step", type=int, default=0, help="CPU baseline renders every n-th row (0: every row for the headline workload, one row per thread otherwise)")
     args = ap.parse_args()
 
     import torch
@@ -104,13 +108,11 @@ def main():
     torch.cuda.set_device(device)
 
     from raytracing_amd import _native
-    from raytracing_amd.flatten import flatten_scene
     from raytracing_amd.tiles import gather_frame, partition_rows, sum_counters
-    from raytracing_amd.workloads import get_workload
+    from raytracing_amd.workloads import get_flat_workload
 
-    scene, options = get_workload(args.workload)
+    flat, options = get_flat_workload(args.workload)
     seed = 0
-    flat = flatten_scene(scene)
     ctx = _native.Context(local_rank)
     ctx.upload(flat)
     H, W = options["height"], options["width"]
@@ -149,7 +151,7 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    keys = ["queries", "rays_api", "tri_tests", "sphere_tests", "shadow_queries", "trace_queries", "nodes"]
+    keys = ["queries", "rays_api", "tri_tests", "sphere_tests", "aabb_tests", "shadow_queries", "trace_queries", "nodes"]
     totals = dict(zip(keys, sum_counters([first_stats[k] for k in keys], device=device)))
 
     if rank == 0:
@@ -182,8 +184,22 @@ def main():
         if tr:
             line["roofline"]["traffic"] = tr[0]["hbm_bytes_per_launch"]
             line["roofline"]["traffic_source"] = "profiles/" + tr[1]
+        if last["aabb_tests"] > 0:
+            # LBVH traversal: HBM roofline.  Algorithmic bytes: 64 B per node visited (the boxes and links of its
+            # two children), 48 B per triangle test (plane row + two barycentric rows), 32 B per sphere test.
+            nbytes = 64.0 * (last["aabb_tests"] / 2) + 48.0 * last["tri_tests"] + 32.0 * last["sphere_tests"]
+            gbs = nbytes / level_s / 1e9 if level_s > 0 else 0.0
+            line["roofline"] = {"bound": "hbm", "kernel": "k_level (LBVH traversal)", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                                "launches_per_frame": last["n_k_level"],
+                                "avg_launch_ms": round(last["ms_k_level"] / max(1, last["n_k_level"]), 5),
+                                "bytes_per_launch": nbytes / max(1, last["n_k_level"]),
+                                "nodes_visited_per_query": round(last["aabb_tests"] / 2 / max(1, last["queries"]), 2),
+                                "tri_tests_per_query": round(last["tri_tests"] / max(1, last["queries"]), 2),
+                                "frame_device_ms": round(last["ms_device"], 4), "resolve_ms": round(last["ms_resolve"], 4)}
+            line["metric"] = f"Mrays/s (primary+secondary closest-hit queries), {args.workload}"
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(flat, options, seed)
+            line["cpu_baseline"] = cpu_baseline(flat, options, seed, row_step=args.cpu_row_step or (1 if args.workload == "cornell_1080p_b4" else 0))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

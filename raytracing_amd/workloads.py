@@ -69,13 +69,14 @@ def cornell_scene(with_light=True, suzanne=False) -> Scene:
     return scene
 
 
-def synthetic_scene(n_random_tris=500_000, grid=500, n_spheres=10_000, seed=1234, extent=50.0, camera=None) -> Scene:
-    """Large synthetic scene: random small triangles in [-extent, extent]^3, a ground grid of 2*grid^2
-    triangles at y = -extent, random spheres, 8 shaders, 4 lights, camera at (0, 0, -2.4 extent) unless given
-    (with the default camera many pixel rays meet the regular ground grid exactly on its edges)."""
+_SYNTHETIC_SHADERS = [(0, 1, (220, 220, 220)), (0.5, 1, (200, 80, 80)), (1, 1, (80, 200, 80)), (1, 1, (80, 80, 200)),
+                      (0, 0.5, (240, 240, 240)), (0.5, 0.5, (200, 200, 80)), (1, 0.5, (80, 200, 200)), (1, 1, (180, 180, 180))]
+_SYNTHETIC_LIGHTS = [(0, 40, -60), (-40, 30, 0), (40, 30, 0), (0, 45, 40)]
+
+
+def _synthetic_arrays(n_random_tris, grid, n_spheres, seed, E):
+    """Geometry of the synthetic scene: triangles [T, 3, 3], shader pick per triangle, sphere centres and radii."""
     rng = np.random.default_rng(seed)
-    scene = Scene()
-    E = float(extent)
     centres = rng.uniform(-E, E, (n_random_tris, 3))
     e1 = rng.uniform(-0.5, 0.5, (n_random_tris, 3))
     e2 = rng.uniform(-0.5, 0.5, (n_random_tris, 3))
@@ -89,24 +90,67 @@ def synthetic_scene(n_random_tris=500_000, grid=500, n_spheres=10_000, seed=1234
     p01 = p00 + [0, 0, step]
     p11 = p00 + [step, 0, step]
     ground = np.concatenate([np.stack([p00, p01, p10], 1), np.stack([p10, p01, p11], 1)])
-    allv = np.concatenate([tri, ground]).reshape(-1, 3)
+    allv = np.concatenate([tri, ground])
+    pick = rng.integers(0, 8, len(allv))
+    sc = rng.uniform(-E, E, (n_spheres, 3))
+    sr = rng.uniform(0.1, 0.6, n_spheres)
+    return allv, pick, sc, sr
+
+
+def synthetic_flat(n_random_tris=500_000, grid=500, n_spheres=10_000, seed=1234, extent=50.0, camera=None):
+    """The flattened form of ``synthetic_scene(...)`` built straight from arrays: a million-triangle scene as
+    a Python object graph takes minutes and gigabytes, the arrays take a second.  Same result as
+    ``flatten_scene(synthetic_scene(...))`` (tests/test_scene_api.py checks it on a small instance)."""
+    from .flatten import OBJ_LIGHT, OBJ_MESH, OBJ_OTHER, OBJ_SPHERE, FlatScene
+    E = float(extent)
+    allv, pick, sc, sr = _synthetic_arrays(n_random_tris, grid, n_spheres, seed, E)
+    T, S, L = len(allv), n_spheres, len(_SYNTHETIC_LIGHTS)
+    n = 1 + S + L + 1
+    default = (1.0, 1.0, (200.0, 200.0, 200.0))  # Shader(): roughness, reflectivity, colour
+    eight = [(float(r), float(f), tuple(float(c) for c in col)) for r, f, col in _SYNTHETIC_SHADERS]
+    table = [default] + eight + [eight[i % 8] for i in range(S)] + [default] * (L + 1)
+    obj_type = np.array([OBJ_MESH] + [OBJ_SPHERE] * S + [OBJ_LIGHT] * L + [OBJ_OTHER], np.int32)
+    cam = tuple(float(c) for c in (camera if camera is not None else (0.0, 0.0, -2.4 * E)))
+    lights = np.array(_SYNTHETIC_LIGHTS, np.float64) * E / 50.0
+    center = np.concatenate([np.zeros((1, 3)), sc, lights, np.array([cam])])
+    radius = np.concatenate([[0.5], (2 * sr) / 2, np.full(L + 1, 0.5)])
+    tri_count = np.zeros(n, np.int32)
+    tri_count[0] = T
+    ior = np.ones(n)
+    ior[0] = 1.3
+    strength = np.zeros(n)
+    strength[1 + S:1 + S + L] = 1.0
+    shader0 = np.concatenate([[0], 9 + np.arange(S + L + 1)]).astype(np.int32)
+    c = np.ascontiguousarray
+    return FlatScene(
+        obj_type=obj_type, obj_tri_begin=np.zeros(n, np.int32), obj_tri_count=tri_count, obj_center=c(center, np.float64),
+        obj_radius=c(radius, np.float64), obj_ior=ior, obj_strength=strength, obj_shader0=shader0,
+        tri_verts=c(allv, np.float64), tri_shader=(pick + 1).astype(np.int32),
+        shader_color=np.array([t[2] for t in table], np.float64), shader_rough=np.array([t[0] for t in table], np.float64),
+        shader_refl=np.array([t[1] for t in table], np.float64), shader_emis=np.zeros(len(table)),
+        light_pos=c(lights, np.float64), light_strength=np.ones(L), light_color=np.full((L, 3), 200.0),
+        cam_pos=cam, cam_euler=(0.0, 0.0, 0.0), cam_zlen=1.0, obj_ids=list(range(n)))
+
+
+def synthetic_scene(n_random_tris=500_000, grid=500, n_spheres=10_000, seed=1234, extent=50.0, camera=None) -> Scene:
+    """Large synthetic scene: random small triangles in [-extent, extent]^3, a ground grid of 2*grid^2
+    triangles at y = -extent, random spheres, 8 shaders, 4 lights, camera at (0, 0, -2.4 extent) unless given
+    (with the default camera many pixel rays meet the regular ground grid exactly on its edges)."""
+    scene = Scene()
+    E = float(extent)
+    allv, pick, sc, sr = _synthetic_arrays(n_random_tris, grid, n_spheres, seed, E)
+    allv = allv.reshape(-1, 3)
     mesh = Mesh([Vec3(*map(float, p)) for p in allv], [(3 * i, 3 * i + 1, 3 * i + 2) for i in range(len(allv) // 3)])
     obj = Object(scene=scene, name="Soup", mesh=mesh)
-    shaders = [Shader(roughness=r, reflectivity=f, color=RGB(*c))
-               for (r, f, c) in [(0, 1, (220, 220, 220)), (0.5, 1, (200, 80, 80)), (1, 1, (80, 200, 80)), (1, 1, (80, 80, 200)),
-                                 (0, 0.5, (240, 240, 240)), (0.5, 0.5, (200, 200, 80)), (1, 0.5, (80, 200, 200)), (1, 1, (180, 180, 180))]]
-    nf = len(mesh.faces)
-    pick = rng.integers(0, 8, nf)
+    shaders = [Shader(roughness=r, reflectivity=f, color=RGB(*c)) for (r, f, c) in _SYNTHETIC_SHADERS]
     for k, sh in enumerate(shaders):
         obj.setShader(sh, np.nonzero(pick == k)[0].tolist())
     obj.material = Material(ior=1.3)
-    sc = rng.uniform(-E, E, (n_spheres, 3))
-    sr = rng.uniform(0.1, 0.6, n_spheres)
     for i in range(n_spheres):
         s = Sphere(scene=scene, name=f"S{i}", position=Vec3(*map(float, sc[i])))
         s.scale = Scale(float(2 * sr[i]), float(2 * sr[i]), float(2 * sr[i]))
         s.setShader(shaders[i % 8])
-    for i, pos in enumerate([(0, 40, -60), (-40, 30, 0), (40, 30, 0), (0, 45, 40)]):
+    for i, pos in enumerate(_SYNTHETIC_LIGHTS):
         Light(scene=scene, name=f"L{i}", position=Vec3(*(float(q) * E / 50.0 for q in pos)), strength=1.0)
     _camera(scene, position=camera if camera is not None else (0, 0, -2.4 * E), length=20)
     return scene
@@ -135,6 +179,24 @@ WORKLOADS = {
 }
 
 
+# Workloads too large for an object graph: name -> (flat-scene factory, options)
+FLAT_WORKLOADS = {
+    "synthetic_1m_4k_b2": (lambda: synthetic_flat(), dict(width=3840, height=2160, bounces=2, samples=1, ambient=(20, 20, 20))),
+    "synthetic_200k_1080p_b2": (lambda: synthetic_flat(100_000, 224, 2000, extent=12.0, camera=(0.3713, 0.2117, -28.8)),
+                                dict(width=1920, height=1080, bounces=2, samples=1, ambient=(20, 20, 20))),
+}
+
+
 def get_workload(name: str):
     factory, options = WORKLOADS[name]
     return factory(), dict(options)
+
+
+def get_flat_workload(name: str):
+    """-> (FlatScene, options) for any workload name."""
+    if name in FLAT_WORKLOADS:
+        factory, options = FLAT_WORKLOADS[name]
+        return factory(), dict(options)
+    from .flatten import flatten_scene
+    scene, options = get_workload(name)
+    return flatten_scene(scene), options

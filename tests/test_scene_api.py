@@ -144,3 +144,13 @@ def test_make_opts_layout():
     o = make_opts(dict(width=5, height=7, bounces=2, samples=3, lights=False, ambient=(1, 2, 3)), seed=9, row_stride=4)
     assert (o.width, o.height, o.bounces, o.samples, o.lights, o.seed, o.row_stride) == (5, 7, 2, 3, 0, 9, 4)
     assert list(o.ambient) == [1.0, 2.0, 3.0]
+
+
+def test_synthetic_flat_equals_flattened_object_graph():
+    import dataclasses
+    from raytracing_amd.workloads import synthetic_flat, synthetic_scene
+    kw = dict(n_random_tris=60, grid=3, n_spheres=11, extent=12.0, camera=(0.3, 0.2, -28.8))
+    a, b = flatten_scene(synthetic_scene(**kw)), synthetic_flat(**kw)
+    for f in dataclasses.fields(a):
+        x, y = np.asarray(getattr(a, f.name)), np.asarray(getattr(b, f.name))
+        assert x.dtype == y.dtype and np.array_equal(x, y), f.name
