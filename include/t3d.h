@@ -174,6 +174,17 @@ int t3d_trace_pixel(t3d_ctx* ctx, const t3d_opts* opts, int x, int y, int sample
                     int capacity);
 
 /*
+ * The same for an explicit initial ray: Photon.trace(ray, bounces, lights) followed by computeColor
+ * (T3DR.py:959-1083), the pair Debug.inspect calls for a picked pixel (T3DR.py:455-469).  `direction` is
+ * normalised like Ray.__init__ does (T3DE.py:126-130); `ior` / `inside_object` are ray.ior and the index of
+ * ray.object in the scene's object list (-1 = none); opts->bounces and opts->lights play the parts of the
+ * `bounces` and `lights` arguments; (key_x, key_y, key_sample) select the random numbers of the diffuse
+ * directions the way a pixel position and sample number do in a render.
+ */
+int t3d_trace_ray(t3d_ctx* ctx, const t3d_opts* opts, const float* origin, const float* direction, float ior,
+                  int inside_object, int key_x, int key_y, int key_sample, t3d_node* nodes, int capacity);
+
+/*
  * Closest hit for n arbitrary rays (Photon.getFirstCollision, T3DR.py:654-730; used for picking,
  * explorer.py:1351-1355).  origins/dirs [n*3] (dirs are normalised by the library like
  * Ray.__init__, T3DE.py:128); out_obj/out_face [n] (-1 = miss), out_t [n], out_dirflag [n]

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("T3D_HIP_LIB") or os.path.join(os.path.dirname(os.path
 ABI_VERSION = 1
 
 SYMBOLS = ("t3d_abi_version", "t3d_device_count", "t3d_create", "t3d_destroy", "t3d_last_error",
-           "t3d_upload_scene", "t3d_render_rows", "t3d_render_rows_device", "t3d_trace_pixel",
+           "t3d_upload_scene", "t3d_render_rows", "t3d_render_rows_device", "t3d_trace_pixel", "t3d_trace_ray",
            "t3d_closest_hits", "t3d_last_call_stats", "t3d_set_timing", "t3d_set_accel")
 
 
@@ -65,6 +65,9 @@ def load():
                                            C.c_void_p, C.c_void_p, C.c_void_p, P(Stats)]
     lib.t3d_trace_pixel.restype = C.c_int
     lib.t3d_trace_pixel.argtypes = [C.c_void_p, P(Opts), C.c_int, C.c_int, C.c_int, P(Node), C.c_int]
+    lib.t3d_trace_ray.restype = C.c_int
+    lib.t3d_trace_ray.argtypes = [C.c_void_p, P(Opts), P(C.c_float), P(C.c_float), C.c_float, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  P(Node), C.c_int]
     lib.t3d_closest_hits.restype = C.c_int
     lib.t3d_closest_hits.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -175,6 +178,17 @@ class Context:
         cap = min(65536, (1 << (opts.bounces + 1)) - 1)
         buf = (Node * cap)()
         n = self._check(self._lib.t3d_trace_pixel(self._h, C.byref(opts), x, y, sample, buf, cap), "t3d_trace_pixel")
+        return [buf[i] for i in range(n)]
+
+    def trace_ray(self, options: dict, origin, direction, ior=1.0, inside_object=-1, key=(0, 0, 0), seed: int = 0):
+        """Tree of one explicit ray; ``options['bounces']`` / ``['lights']`` are the arguments of ``Photon.trace``."""
+        opts = make_opts(options, seed)
+        cap = min(65536, (1 << (opts.bounces + 1)) - 1)
+        buf = (Node * cap)()
+        o = (C.c_float * 3)(*[float(c) for c in origin])
+        d = (C.c_float * 3)(*[float(c) for c in direction])
+        n = self._check(self._lib.t3d_trace_ray(self._h, C.byref(opts), o, d, float(ior), int(inside_object), int(key[0]),
+                                                int(key[1]), int(key[2]), buf, cap), "t3d_trace_ray")
         return [buf[i] for i in range(n)]
 
     def closest_hits(self, origins, dirs, lights=True, back_cull=True):

@@ -119,8 +119,10 @@ struct RenderParams {
     int n0;          // primary samples of this launch (rows * width * samples)
     int cap;         // capacity of one level's ray queue / node array (multiple of T3D_SHARDS * 64)
     int want_debug;  // record t3d_node entries (t3d_trace_pixel)
-    int px0, py0, sample0;  // single-pixel mode (t3d_trace_pixel): the only pixel / sample traced
-    int single;
+    int px0, py0, sample0;  // single-sample mode (t3d_trace_pixel / t3d_trace_ray): key of the random numbers
+    int single;             // 0 image band, 1 one pixel sample (camera ray), 2 one explicit ray
+    float ray_o[3], ray_d[3], ray_ior;  // single == 2: the initial ray (unit direction) ...
+    int ray_obj;                        // ... and the object it travels inside (-1 none)
 };
 
 // One queued ray (64 B).
@@ -721,7 +723,14 @@ __device__ __forceinline__ void load_ray(const DevScene& sc, const RenderParams&
         in.px = pix - ly * rp.width;
         in.py = rp.row0 + ly * rp.row_stride;
         if (rp.single) { in.px = rp.px0; in.py = rp.py0; in.smp = rp.sample0; }
-        if (LEVEL0) camera_ray(sc.cam, rp, in.px, in.py, in.o, in.d);
+        if (LEVEL0) {
+            if (rp.single == 2) {
+                in.o = mk(rp.ray_o[0], rp.ray_o[1], rp.ray_o[2]); in.d = mk(rp.ray_d[0], rp.ray_d[1], rp.ray_d[2]);
+                in.ior = rp.ray_ior; in.inside_obj = rp.ray_obj;
+            } else {
+                camera_ray(sc.cam, rp, in.px, in.py, in.o, in.d);
+            }
+        }
     }
 }
 
@@ -1347,7 +1356,11 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
     for (int k = 0; k < 3; ++k) rp.ambient[k] = (float)o->ambient[k];
     rp.cap = (int)c->cap_alloc;
     rp.n0 = (int)n0;
-    if (single) { rp.single = 1; rp.px0 = single->px0; rp.py0 = single->py0; rp.sample0 = single->sample0; rp.want_debug = 1; rp.width = o->width; }
+    if (single) {
+        rp.single = single->single; rp.px0 = single->px0; rp.py0 = single->py0; rp.sample0 = single->sample0; rp.want_debug = 1;
+        for (int k = 0; k < 3; ++k) { rp.ray_o[k] = single->ray_o[k]; rp.ray_d[k] = single->ray_d[k]; }
+        rp.ray_ior = single->ray_ior; rp.ray_obj = single->ray_obj;
+    }
 
     HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), st));
     TraceOut out{c->d_sample_color, d_prim, d_prim_t, d_dbg, dbg_cap};
@@ -1509,27 +1522,23 @@ extern "C" int t3d_render_rows(t3d_ctx* c, const t3d_opts* o, int row0, int nrow
     return T3D_OK;
 }
 
-extern "C" int t3d_trace_pixel(t3d_ctx* c, const t3d_opts* o, int x, int y, int sample, t3d_node* nodes, int capacity) {
-    int rc = check_opts(c, o, 0, 1);
-    if (rc) return rc;
-    if (!nodes || capacity <= 0 || x < 0 || y < 0 || x >= o->width || y >= o->height || sample < 0) { c->err = "t3d_trace_pixel: bad argument"; return T3D_E_INVALID; }
+// One initial ray through every level; its tree in depth-first order (bounce child before transmit child).
+static int trace_single(t3d_ctx* c, const t3d_opts* o, const RenderParams& single, int row, t3d_node* nodes, int capacity) {
     HIPCHK(c, hipSetDevice(c->device));
     const int worst = (1 << (o->bounces + 1)) - 1;
     const int dbg_cap = worst < 65536 ? worst : 65536;
     t3d_node* d_dbg = nullptr;
     HIPCHK(c, hipMalloc((void**)&d_dbg, sizeof(t3d_node) * dbg_cap));
-    RenderParams single{};
-    single.px0 = x; single.py0 = y; single.sample0 = sample;
     t3d_stats st{};
     // capacity factor: a single sample can branch at every level
     // all nodes of a single-pixel tree land in one queue shard: a shard must hold a full level (2^bounces rays)
     int factor = T3D_SHARDS * (1 << o->bounces);
-    rc = render_band(c, o, y, 1, factor, nullptr, nullptr, nullptr, nullptr, c->stream, &st, &single, d_dbg, dbg_cap);
+    int rc = render_band(c, o, row, 1, factor, nullptr, nullptr, nullptr, nullptr, c->stream, &st, &single, d_dbg, dbg_cap);
     int n = 0;
     if (!rc) {
         n = c->h_cnt->n_dbg < dbg_cap ? c->h_cnt->n_dbg : dbg_cap;
         std::vector<t3d_node> tmp((size_t)(n > 0 ? n : 1));
-        if (n > 0 && hipMemcpy(tmp.data(), d_dbg, sizeof(t3d_node) * n, hipMemcpyDeviceToHost) != hipSuccess) { rc = T3D_E_DEVICE; c->err = "t3d_trace_pixel: copy failed"; }
+        if (n > 0 && hipMemcpy(tmp.data(), d_dbg, sizeof(t3d_node) * n, hipMemcpyDeviceToHost) != hipSuccess) { rc = T3D_E_DEVICE; c->err = "trace: copy of the node records failed"; }
         if (!rc) {
             // depth-first order, bounce child (2n) before transmit child (2n+1)
             std::vector<int> order;
@@ -1544,12 +1553,36 @@ extern "C" int t3d_trace_pixel(t3d_ctx* c, const t3d_opts* o, int x, int y, int 
                 if (2 * hidx + 1 < 65536) { stack.push_back(2 * hidx + 1); stack.push_back(2 * hidx); }
             }
             int m = (int)order.size();
-            if (m > capacity) { rc = T3D_E_CAPACITY; c->err = "t3d_trace_pixel: node buffer too small"; }
+            if (m > capacity) { rc = T3D_E_CAPACITY; c->err = "trace: node buffer too small"; }
             else { for (int i = 0; i < m; ++i) nodes[i] = tmp[order[i]]; n = m; }
         }
     }
     hipFree(d_dbg);
     return rc ? rc : n;
+}
+
+extern "C" int t3d_trace_pixel(t3d_ctx* c, const t3d_opts* o, int x, int y, int sample, t3d_node* nodes, int capacity) {
+    int rc = check_opts(c, o, 0, 1);
+    if (rc) return rc;
+    if (!nodes || capacity <= 0 || x < 0 || y < 0 || x >= o->width || y >= o->height || sample < 0) { c->err = "t3d_trace_pixel: bad argument"; return T3D_E_INVALID; }
+    RenderParams single{};
+    single.single = 1; single.px0 = x; single.py0 = y; single.sample0 = sample;
+    return trace_single(c, o, single, y, nodes, capacity);
+}
+
+extern "C" int t3d_trace_ray(t3d_ctx* c, const t3d_opts* o, const float* origin, const float* direction, float ior, int inside_object,
+                             int key_x, int key_y, int key_sample, t3d_node* nodes, int capacity) {
+    int rc = check_opts(c, o, 0, 1);
+    if (rc) return rc;
+    if (!nodes || capacity <= 0 || !origin || !direction || key_x < 0 || key_y < 0 || key_sample < 0 || inside_object < -1 ||
+        inside_object >= c->n_objects) { c->err = "t3d_trace_ray: bad argument"; return T3D_E_INVALID; }
+    const double len = sqrt((double)direction[0] * direction[0] + (double)direction[1] * direction[1] + (double)direction[2] * direction[2]);
+    if (!(len > 0)) { c->err = "t3d_trace_ray: zero direction"; return T3D_E_INVALID; }
+    RenderParams single{};
+    single.single = 2; single.px0 = key_x; single.py0 = key_y; single.sample0 = key_sample;
+    for (int k = 0; k < 3; ++k) { single.ray_o[k] = origin[k]; single.ray_d[k] = (float)(direction[k] / len); }  // Ray.__init__ normalises (T3DE.py:126-130)
+    single.ray_ior = ior; single.ray_obj = inside_object;
+    return trace_single(c, o, single, 0, nodes, capacity);
 }
 
 extern "C" int t3d_closest_hits(t3d_ctx* c, int n, const float* origins, const float* dirs, int lights, int back_cull,

@@ -263,12 +263,108 @@ class Photon:
             return 1
         return 1 - shader.reflectivity
 
+    def getDirectLight(self, collisionInfo):
+        """``(light colour, intensity)`` at a hit (T3DR.py:820-900): per light a diffuse and a mirror term, the
+        shadow ray's visibility and the distance attenuation.  The shadow rays of all lights are traced by the
+        device in one call; ``rays`` grows by one per light as in the reference."""
+        point, obj = collisionInfo["point"], collisionInfo["object"]
+        lights = self.getAllLightsPos()
+        total_color, total = RGB(0, 0, 0), 0
+        if not lights:
+            return total_color, total
+        shader = obj.getShader(collisionInfo["face"])
+        rough = shader.roughness if shader else 1
+        normal = collisionInfo["normal"].normalise()
+        view = (self._camera_scene().camera.position - point).normalise()
+        rays = []
+        for pos, _, _ in lights:
+            to_light = (pos - point).normalise()
+            rays.append(Ray(point + to_light * 0.2, to_light, 1, None))
+        self.rays += len(rays)
+        vis = self._visibilities(rays)
+        for (pos, strength, color), ray, v in zip(lights, rays, vis):
+            lv = ray.direction.normalise()
+            diffuse = max(0, lv.dot(normal))
+            mirror = (normal * lv.dot(normal) * 2) - lv
+            specular = 0 if mirror.normalise().dot(view) < 0.96 else 1
+            att = self.getAttenuation((pos - point).magnitude())
+            total += (diffuse * rough + specular * (1 - rough)) * strength * v * att
+            total_color = total_color + color * 0.6
+        return total_color, total
+
+    def _visibilities(self, rays):
+        """getVisibility (T3DR.py:762-778) for a batch of rays, one device call."""
+        ctx = self._prepare()
+        hit = ctx.closest_hits([[*r.start] for r in rays], [[*r.direction] for r in rays], True, False)
+        objects = self._camera_scene().objects
+        out = []
+        for oi, fi in zip(hit["obj"], hit["face"]):
+            if oi < 0 or objects[oi].type == "light":
+                out.append(1)
+                continue
+            obj = objects[int(oi)]
+            shader = obj.getShader(obj.mesh.faces[int(fi)] if fi >= 0 else None)
+            out.append(1 if (obj.type == "mesh" and shader.emissionStrength > 0) else 1 - shader.reflectivity)
+        return out
+
+    def trace(self, ray, bounces, lights=False):
+        """Trace tree of one ray (T3DR.py:959-1001), built by the device (``t3d_trace_ray``).  Every node
+        carries its resolved colour, so ``computeColor`` of such a tree costs nothing.  The diffuse
+        directions are keyed by ``ray.key = (x, y, sample)`` when the ray has one, else (0, 0, 0)."""
+        ctx = self._prepare()
+        objects = self._camera_scene().objects
+        inside = -1
+        if ray.object is not None:
+            for k, o in enumerate(objects):
+                if o is ray.object or o.id == getattr(ray.object, "id", None):
+                    inside = k
+                    break
+        opts = dict(self._native_options(), bounces=int(bounces), lights=bool(lights))
+        nodes = ctx.trace_ray(opts, ray.start, ray.direction, ray.ior, inside, getattr(ray, "key", (0, 0, 0)),
+                              int(self.options.get("seed", 0)))
+        self.rays += 1
+        return self._tree_from_nodes(nodes, objects)
+
+    def computeColor(self, trace):
+        """Colour of a trace tree, bottom-up with a clamp on every addition (T3DR.py:1004-1083).  Trees that
+        came from the device already hold the colour of every node; a tree assembled by the caller is
+        evaluated here, its shadow rays on the device."""
+        if trace is None:
+            return self.options["ambient"]
+        info = trace.collisionInfo
+        if "color" in info:
+            return RGB(*info["color"])
+        obj = info["object"]
+        camera = self._camera_scene().camera
+        ambient = self.options["ambient"]
+        if obj.type == "light":
+            att = self.getAttenuation((info["point"] - camera.position).magnitude())
+            return (obj.shaders[0].color * obj.strength * att).clamp()
+        shader = obj.getShader(info["face"])
+        if obj.type == "mesh" and shader.emissionStrength > 0:
+            att = self.getAttenuation((info["point"] - camera.position).magnitude())
+            return (shader.color * shader.emissionStrength * att).clamp()
+        slot = []
+        for child in (trace.left, trace.right):
+            if child is None:
+                slot.append((ambient * (2 / 255), self.getAttenuation(0)))
+            else:
+                slot.append((self.computeColor(child),
+                             self.getAttenuation((child.collisionInfo["point"] - trace.ray.start).magnitude())))
+        refl = shader.reflectivity
+        indirect = (slot[0][0] * refl * slot[0][1]) + (slot[1][0] * (1 - refl) * slot[1][1] * 1.4)
+        light_color, intensity = self.getDirectLight(info)
+        direct = ((shader.color * intensity) + (light_color * intensity * (2 / 255))) * refl
+        return (indirect + direct + (shader.color * ambient * (1 / 255))).clamp()
+
     def _trace_pixel_tree(self, options, x, y, sample, seed):
         ctx = self._prepare()
         nodes = ctx.trace_pixel(options, x, y, sample, seed)
+        return self._tree_from_nodes(nodes, self.transformedScene.objects)
+
+    def _tree_from_nodes(self, nodes, objects):
         if not nodes:
             return None
-        objects = self.transformedScene.objects
         by_heap = {}
         for n in nodes:
             obj = objects[n.obj]

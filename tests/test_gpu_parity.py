@@ -227,3 +227,55 @@ def test_photon_api_end_to_end(gpu_ctx):
     hit = photon.getFirstCollision(photon.getRay(photon.pixelToVector(32, 30)), lights=True, backCull=False)
     assert hit["object"] is not None and hit["t"] > 0
     assert photon.getFirstCollision(photon.getRay(photon.pixelToVector(0, 0)), True)["object"] is None
+
+
+def test_photon_trace_compute_color_direct_light(gpu_ctx):
+    """Photon.trace / computeColor / getDirectLight for explicit rays (the Debug.inspect callers, T3DR.py:455-469)."""
+    import T3DE
+    import T3DR
+    scene = T3DE.Scene.fromJSON(str(__import__("os").path.join(__import__("conftest").SCENES, "cornellScene.json")))
+    opts = {"width": 64, "height": 48, "bounces": 3, "samples": 2, "seed": 5}
+    photon = T3DR.Photon(scene, opts)
+    rendered = photon.render()
+
+    def strip(node):      # the same tree without the device's colours: computeColor must evaluate it on the host
+        if node is None:
+            return None
+        info = {k: v for k, v in node.collisionInfo.items() if k != "color"}
+        out = T3DE.TraceTreeNode(node.ray, info)
+        out.left, out.right = strip(node.left), strip(node.right)
+        return out
+
+    def heaps(node, h=1):
+        return [] if node is None else [h] + heaps(node.left, 2 * h) + heaps(node.right, 2 * h + 1)
+
+    checked = 0
+    for (x, y) in [(32, 30), (40, 33), (20, 36), (45, 24), (0, 0)]:
+        for s in range(2):
+            want = rendered.traces[(x, y)][s]
+            ray = photon.getRay(photon.pixelToVector(x, y))
+            ray.key = (x, y, s)
+            got = photon.trace(ray, 3, lights=True)
+            assert heaps(got) == heaps(want)
+            if want is None:
+                assert [round(c) for c in photon.computeColor(None)] == [20, 20, 20]
+                continue
+            a, b = photon.computeColor(got), photon.computeColor(want)
+            assert np.allclose(list(a), list(b), atol=1e-4)
+            host = photon.computeColor(strip(got))          # float64 on the host, shadow rays on the device
+            assert np.allclose(list(host), list(a), atol=RADIANCE_TOL), (x, y, s, list(host), list(a))
+            checked += 1
+    assert checked >= 6
+    # getDirectLight alone: two lights in this scene, intensity bounded by the sum of strengths
+    node = rendered.traces[(32, 30)][0]
+    before = photon.rays
+    color, intensity = photon.getDirectLight(node.collisionInfo)
+    assert photon.rays == before + len(photon.getAllLightsPos())
+    assert 0 <= intensity <= sum(l[1] for l in photon.getAllLightsPos()) and max(color) <= 255
+    # a ray that starts inside the glass cube keeps its medium: first hit is the cube seen from inside
+    cube = next(o for o in photon.transformedScene.objects if o.type == "mesh" and o.material.ior != 1)
+    centre = cube.boundingBox()
+    mid = T3DE.Vec3(*[(centre[0][k] + centre[1][k]) / 2 for k in range(3)])
+    inside = T3DE.Ray(mid, T3DE.Vec3(0.3, 0.2, 1).normalise(), cube.material.ior, cube)
+    tree = photon.trace(inside, 1, lights=True)
+    assert tree is not None and tree.collisionInfo["object"].id == cube.id and tree.collisionInfo["direction"] == 1
