@@ -125,3 +125,43 @@ def test_large_scene_properties(gpu_ctx, oracle_mod):
     frag = oracle_mod.primary_fragility(flat, dict(opt), row0=0, row_stride=step)
     sub = dict(bgr=full["bgr"][::step], prim=full["prim"][::step], prim_t=full["prim_t"][::step], radiance=None, stats=ref["stats"])
     check_against_oracle(sub, ref, frag)
+
+
+def _frame_properties(ctx, oracle_mod, flat, opt, row_step, parts=8):
+    """Determinism, independence of the row partition, and the oracle on every row_step-th row."""
+    H = opt["height"]
+    full = ctx.render_rows(opt, seed=0, want_primary=True)
+    again = ctx.render_rows(opt, seed=0)
+    assert np.array_equal(full["bgr"], again["bgr"]) and full["stats"]["queries"] == again["stats"]["queries"]
+    frame = np.empty_like(full["bgr"])
+    rays = 0
+    for r in range(parts):
+        o = ctx.render_rows(opt, seed=0, row0=r, nrows=H // parts, row_stride=parts)
+        frame[r::parts] = o["bgr"]
+        rays += o["stats"]["rays_api"]
+    assert np.array_equal(frame, full["bgr"]) and rays == full["stats"]["rays_api"]
+    ref = oracle_mod.render(flat, opt, seed=0, row0=0, row_stride=row_step, want_radiance=False)
+    frag = oracle_mod.primary_fragility(flat, dict(opt), row0=0, row_stride=row_step)
+    sub = dict(bgr=full["bgr"][::row_step], prim=full["prim"][::row_step], prim_t=full["prim_t"][::row_step], radiance=None,
+               stats=ref["stats"])
+    check_against_oracle(sub, ref, frag)
+    return full
+
+
+def test_suzanne_4k_full_size(gpu_ctx, oracle_mod):
+    """suzanne.stl inside the box, 3840x2160, 4 bounces (1 018 triangles: LBVH)."""
+    from raytracing_amd.workloads import get_flat_workload
+    flat, opt = get_flat_workload("suzanne_4k_b4")
+    gpu_ctx.set_accel("auto")
+    gpu_ctx.upload(flat)
+    full = _frame_properties(gpu_ctx, oracle_mod, flat, opt, row_step=216)
+    assert full["stats"]["aabb_tests"] > 0
+
+
+def test_cornell2_8k_full_size(gpu_ctx, oracle_mod):
+    """cornellScene2.json with three added lights, 7680x4320, 8 bounces: the frame is split into bands."""
+    from raytracing_amd.workloads import get_flat_workload
+    flat, opt = get_flat_workload("cornell2_8k_b8")
+    gpu_ctx.set_accel("auto")
+    gpu_ctx.upload(flat)
+    _frame_properties(gpu_ctx, oracle_mod, flat, opt, row_step=432)
