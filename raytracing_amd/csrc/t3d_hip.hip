@@ -257,15 +257,22 @@ __device__ __forceinline__ void plane_groups(const float4* __restrict__ planes, 
         const int k0 = plane_first[g], k1 = plane_first[g + 1];
         const f2 ps = fma2(ds, t, os), pt = fma2(dt, t, ot);
         f2 A = splat(0.0f);
-        for (int k = k0; k < k1; ++k) {
-            const float4 ra = tri_uv[2 * k + 0];
-            const float4 rb = tri_uv[2 * k + 1];
+        auto inside = [&](float4 ra, float4 rb) -> f2 {
             const f2 u = fma2(splat(ra.z), pt, fma2(splat(ra.x), ps, splat(ra.y)));
             const f2 v = fma2(splat(rb.z), pt, fma2(splat(rb.x), ps, splat(rb.y)));
             const f2 w = (splat(1.0f) - u) - v;
             const f2 m = {fminf(fminf(u.x, v.x), w.x), fminf(fminf(u.y, v.y), w.y)};
-            A = fma2(A, splat(2.0f), step01(m, big));
+            return step01(m, big);
+        };
+        // two triangles per step: both row pairs are requested before either is used (one scalar-load wait
+        // per two triangles, and two independent dependency chains for the scheduler)
+        int k = k0;
+        for (; k + 1 < k1; k += 2) {
+            const float4 ra0 = tri_uv[2 * k + 0], rb0 = tri_uv[2 * k + 1], ra1 = tri_uv[2 * k + 2], rb1 = tri_uv[2 * k + 3];
+            const f2 f0 = inside(ra0, rb0), f1 = inside(ra1, rb1);
+            A = fma2(A, splat(4.0f), fma2(f0, splat(2.0f), f1));
         }
+        if (k < k1) A = fma2(A, splat(2.0f), inside(tri_uv[2 * k + 0], tri_uv[2 * k + 1]));
         const uint32_t tt0 = (A.x >= 1.0f) ? tp0 : 0x7f800000u;
         const uint32_t tt1 = (A.y >= 1.0f) ? tp1 : 0x7f800000u;
         const bool cl0 = tt0 < best0, cl1 = tt1 < best1;
