@@ -1,0 +1,30 @@
+"""What one rank of an N-GPU run does per frame, timed on one GPU: rows r, r+N, ... of the benchmark frame
+(no gather).  Shows the fixed per-frame cost that limits strong scaling."""
+import sys, time
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from raytracing_amd import _native
+from raytracing_amd.workloads import get_flat_workload
+flat, opt = get_flat_workload("cornell_1080p_b4")
+ctx = _native.Context(0); ctx.upload(flat)
+H, W = opt["height"], opt["width"]
+dev = torch.device("cuda", 0)
+stream = torch.cuda.current_stream(dev).cuda_stream
+for n in ([int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]):
+    rows = H // n
+    out = torch.empty((rows, W, 3), dtype=torch.uint8, device=dev)
+    st = ctx.render_rows_device(opt, 0, 0, rows, out.data_ptr(), stream=stream, want_stats=True, row_stride=n)
+    ctx.set_timing(False)
+    for _ in range(3):
+        ctx.render_rows_device(opt, 0, 0, rows, out.data_ptr(), stream=stream, want_stats=False, row_stride=n)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    K = 50
+    for _ in range(K):
+        ctx.render_rows_device(opt, 0, 0, rows, out.data_ptr(), stream=stream, want_stats=False, row_stride=n)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / K * 1e3
+    ctx.set_timing(True)
+    print(f"ranks {n}: rows {rows}  {ms:.4f} ms/frame per rank  queries {st['queries']}  -> speedup bound {0:.2f}" if n == 1 else
+          f"ranks {n}: rows {rows}  {ms:.4f} ms/frame per rank  queries {st['queries']}")
