@@ -90,6 +90,7 @@ typedef struct t3d_opts {
 } t3d_opts;
 
 #define T3D_STATS_N_COUNTERS 10
+#define T3D_STATS_MAX_LEVELS 16
 typedef struct t3d_stats {
     /* T3D_STATS_N_COUNTERS integer counters first, then the timings */
     uint64_t rays_api;       /* Rendered.rays: primary samples + shadow rays (T3DR.py:842, 1211)     */
@@ -105,6 +106,10 @@ typedef struct t3d_stats {
     double ms_device;        /* device time of the whole call (HIP events on the launch stream)      */
     double ms_k_level;       /* sum of the k_level launch durations                                  */
     double ms_resolve;       /* colour resolve + image store                                         */
+    /* per tree level (0 = primary rays), summed over the bands of the call; levels above bounces stay 0 */
+    uint64_t level_rays[T3D_STATS_MAX_LEVELS];   /* tree rays traced at the level                    */
+    uint64_t level_nodes[T3D_STATS_MAX_LEVELS];  /* shaded nodes created at the level                */
+    double level_ms[T3D_STATS_MAX_LEVELS];       /* duration of the level's k_level launch           */
 } t3d_stats;
 
 /* One trace-tree node as t3d_trace_pixel returns it (TraceTreeNode, T3DE.py:273-280). */

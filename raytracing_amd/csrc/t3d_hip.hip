@@ -130,7 +130,7 @@ struct RayRec {
     float4 o;  // origin, w = ior of the medium the ray travels in
     float4 d;  // unit direction, w = int bits: object the ray is inside (-1 none)
     float4 p;  // parent node's ray.start (attenuation origin, T3DR.py:1062-1064), w = int bits: parent node
-    uint4 k;   // x = pixel-sample index, y = heap index, z = side (0 = reflected slot, 1 = transmitted), w = debug index
+    uint4 k;   // x = pixel-sample index, y = sample << 16 | heap index, z = side (0 = reflected slot, 1 = transmitted), w = pixel hash of the random-number key
 };
 
 // Node arrays (structure of float4 arrays, 64 B per node in total)
@@ -194,11 +194,15 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
-__device__ __forceinline__ V3 keyed_cube(uint32_t seed, uint32_t px, uint32_t py, uint32_t sample, uint32_t heap) {
+// The key is hashed in two steps: the part that belongs to the pixel once per primary ray (it then travels in
+// the ray records), the part that belongs to the ray being generated per draw.
+__device__ __forceinline__ uint32_t keyed_pixel_hash(uint32_t seed, uint32_t px, uint32_t py) {
     uint32_t h = mix32(seed + 0x9E3779B9u);
     h = mix32(h ^ px);
-    h = mix32(h ^ py);
-    h = mix32(h ^ (((sample & 0xFFFFu) << 16) | (heap & 0xFFFFu)));
+    return mix32(h ^ py);
+}
+__device__ __forceinline__ V3 keyed_cube(uint32_t pixel_hash, uint32_t sample_heap) {  // sample << 16 | heap
+    uint32_t h = mix32(pixel_hash ^ sample_heap);
     uint32_t a = mix32(h ^ 0x9E3779B9u) >> 8, b = mix32(h ^ 0x3C6EF372u) >> 8, c = mix32(h ^ 0xDAA66D2Bu) >> 8;
     const float s = 1.0f / 8388608.0f;  // 2^-23: -1 + 2 * bits / 2^24, exact in float32
     return mk(fmaf((float)a, s, -1.0f), fmaf((float)b, s, -1.0f), fmaf((float)c, s, -1.0f));
@@ -514,8 +518,9 @@ struct RayIn {
     V3 o, d, pstart;
     float ior;
     int inside_obj, parent, side;
-    uint32_t ps, heap;
-    int px, py, smp;
+    uint32_t ps, heap;   // pixel-sample index of the root; sample << 16 | heap index of this ray in its tree
+    uint32_t pixel_hash; // keyed_pixel_hash of the root's pixel
+    int px, py, smp;     // level 0 only
     int i;  // index in the level's queue (level 0: sample index)
     bool active;
 };
@@ -582,7 +587,7 @@ __device__ __forceinline__ void process_ray(const DevScene& sc, const DevSphere*
         dbg_idx = atomicAdd(&cnt->n_dbg, 1);
         if (dbg_idx < out.dbg_cap) {
             t3d_node& nd = out.dbg[dbg_idx];
-            nd.heap = (int)in.heap; nd.obj = obj; nd.face = face; nd.direction = dirflag; nd.t = h.t;
+            nd.heap = (int)(in.heap & 0xFFFFu); nd.obj = obj; nd.face = face; nd.direction = dirflag; nd.t = h.t;
             nd.point[0] = P.x; nd.point[1] = P.y; nd.point[2] = P.z;
             nd.normal[0] = Nraw.x; nd.normal[1] = Nraw.y; nd.normal[2] = Nraw.z;
             nd.ray_start[0] = o.x; nd.ray_start[1] = o.y; nd.ray_start[2] = o.z;
@@ -611,6 +616,7 @@ __device__ __forceinline__ void process_ray(const DevScene& sc, const DevSphere*
     V3 tdir = mk(0, 0, 1), bdir = mk(0, 0, 1), tstart = P, bstart = P;
     float t_ior = 1.0f, rough = 1.0f;
     int t_obj = -1;
+    const uint32_t child_heap = (in.heap & 0xFFFF0000u) | ((2u * in.heap) & 0xFFFFu);  // bounce child 2n, transmit child 2n + 1
     if (shaded) {
         DevShader sh = sc.shaders[shader];
         const float refl = sh.refl;
@@ -626,9 +632,9 @@ __device__ __forceinline__ void process_ray(const DevScene& sc, const DevSphere*
                 float ratio = in.ior / n2;
                 float sin2T = ratio * ratio * (1.0f - cosI * cosI);
                 if (!(sin2T > 1.0f)) {
-                    float cosT = __builtin_sqrtf(1.0f - sin2T);
+                    float cosT = __builtin_amdgcn_sqrtf(1.0f - sin2T);
                     V3 spec = madd(d * ratio, Nn, ratio * cosI - cosT);
-                    V3 diff = normalize(keyed_cube(rp.seed, (uint32_t)in.px, (uint32_t)in.py, (uint32_t)in.smp, 2u * in.heap + 1u));
+                    V3 diff = normalize(keyed_cube(in.pixel_hash, child_heap + 1u));
                     if (dot(diff, Nn) > 0.0f) diff = diff * -1.0f;
                     V3 dir = madd(spec * (1.0f - rough), diff, rough);
                     tstart = madd(P, dir, 0.1f);
@@ -639,7 +645,7 @@ __device__ __forceinline__ void process_ray(const DevScene& sc, const DevSphere*
             }
             if (refl != 0.0f) {
                 // bounce (T3DR.py:733-759)
-                V3 diff = normalize(keyed_cube(rp.seed, (uint32_t)in.px, (uint32_t)in.py, (uint32_t)in.smp, 2u * in.heap));
+                V3 diff = normalize(keyed_cube(in.pixel_hash, child_heap));
                 if (dot(diff, N) < 0.0f) diff = diff * -1.0f;
                 V3 spec = madd(d, N, -2.0f * dot(d, N));
                 V3 dir = madd(spec * (1.0f - rough), diff, rough);
@@ -682,7 +688,7 @@ __device__ __forceinline__ void process_ray(const DevScene& sc, const DevSphere*
             r.o = make_float4(tstart.x, tstart.y, tstart.z, t_ior);
             r.d = make_float4(tdir.x, tdir.y, tdir.z, __int_as_float(t_obj));
             r.p = make_float4(o.x, o.y, o.z, __int_as_float((int)(wc.node_base + node)));
-            r.k = make_uint4(in.ps, 2u * in.heap + 1u, 1u, (uint32_t)dbg_idx);
+            r.k = make_uint4(in.ps, child_heap + 1u, 1u, in.pixel_hash);
             rays_out[wc.shard * wc.shard_cap + tloc] = r;
         } else cnt->overflow = 1;
     }
@@ -692,7 +698,7 @@ __device__ __forceinline__ void process_ray(const DevScene& sc, const DevSphere*
             r.o = make_float4(bstart.x, bstart.y, bstart.z, in.ior);
             r.d = make_float4(bdir.x, bdir.y, bdir.z, __int_as_float(in.inside_obj));
             r.p = make_float4(o.x, o.y, o.z, __int_as_float((int)(wc.node_base + node)));
-            r.k = make_uint4(in.ps, 2u * in.heap, 0u, (uint32_t)dbg_idx);
+            r.k = make_uint4(in.ps, child_heap, 0u, in.pixel_hash);
             rays_out[wc.shard * wc.shard_cap + bloc] = r;
         } else cnt->overflow = 1;
     }
@@ -712,31 +718,31 @@ __device__ __forceinline__ void load_ray(const DevScene& sc, const RenderParams&
     in.i = LEVEL0 ? idx : queue_base + idx;
     in.o = mk(0, 0, 0); in.d = mk(0, 0, 1); in.pstart = mk(0, 0, 0);
     in.ior = 1.0f; in.inside_obj = -1; in.parent = -1; in.side = 0;
-    in.ps = 0; in.heap = 1; in.px = 0; in.py = 0; in.smp = 0;
+    in.ps = 0; in.heap = 1; in.pixel_hash = 0; in.px = 0; in.py = 0; in.smp = 0;
     if (in.active) {
         if (LEVEL0) {
             in.ps = (uint32_t)in.i;
             in.parent = in.i;
-        } else {
-            RayRec r = rays_in[in.i];
-            in.o = mk(r.o.x, r.o.y, r.o.z); in.ior = r.o.w;
-            in.d = mk(r.d.x, r.d.y, r.d.z); in.inside_obj = __float_as_int(r.d.w);
-            in.pstart = mk(r.p.x, r.p.y, r.p.z); in.parent = __float_as_int(r.p.w);
-            in.ps = r.k.x; in.heap = r.k.y; in.side = (int)r.k.z;
-        }
-        int pix = (int)in.ps / rp.samples;
-        in.smp = (int)in.ps - pix * rp.samples;
-        int ly = pix / rp.width;
-        in.px = pix - ly * rp.width;
-        in.py = rp.row0 + ly * rp.row_stride;
-        if (rp.single) { in.px = rp.px0; in.py = rp.py0; in.smp = rp.sample0; }
-        if (LEVEL0) {
+            int pix = in.i / rp.samples;
+            in.smp = in.i - pix * rp.samples;
+            int ly = pix / rp.width;
+            in.px = pix - ly * rp.width;
+            in.py = rp.row0 + ly * rp.row_stride;
+            if (rp.single) { in.px = rp.px0; in.py = rp.py0; in.smp = rp.sample0; }
+            in.pixel_hash = keyed_pixel_hash(rp.seed, (uint32_t)in.px, (uint32_t)in.py);
+            in.heap = (((uint32_t)in.smp & 0xFFFFu) << 16) | 1u;
             if (rp.single == 2) {
                 in.o = mk(rp.ray_o[0], rp.ray_o[1], rp.ray_o[2]); in.d = mk(rp.ray_d[0], rp.ray_d[1], rp.ray_d[2]);
                 in.ior = rp.ray_ior; in.inside_obj = rp.ray_obj;
             } else {
                 camera_ray(sc.cam, rp, in.px, in.py, in.o, in.d);
             }
+        } else {
+            RayRec r = rays_in[in.i];
+            in.o = mk(r.o.x, r.o.y, r.o.z); in.ior = r.o.w;
+            in.d = mk(r.d.x, r.d.y, r.d.z); in.inside_obj = __float_as_int(r.d.w);
+            in.pstart = mk(r.p.x, r.p.y, r.p.z); in.parent = __float_as_int(r.p.w);
+            in.ps = r.k.x; in.heap = r.k.y; in.side = (int)r.k.z; in.pixel_hash = r.k.w;
         }
     }
 }
@@ -1308,17 +1314,20 @@ static void fill_stats(t3d_ctx* c, t3d_stats* stats) {
         for (int d = 0; d < levels; ++d) {
             hipEventElapsedTime(&ms, c->ev[d], c->ev[d + 1]);
             stats->ms_k_level += ms;
+            stats->level_ms[d] += ms;
         }
         hipEventElapsedTime(&ms, c->ev[levels], c->ev[n_ev - 1]);
         stats->ms_resolve += ms;
     }
     uint64_t rays = 0, nodes = 0;
     for (int d = 0; d < levels; ++d) {
-        if (d == 0) rays += c->last_n0;
+        uint64_t lr = d == 0 ? c->last_n0 : 0, ln = 0;
         for (int sh = 0; sh < T3D_SHARDS; ++sh) {
-            if (d > 0) rays += (uint64_t)c->h_cnt->n_rays[d][sh].v;
-            nodes += (uint64_t)c->h_cnt->n_nodes[d][sh].v;
+            if (d > 0) lr += (uint64_t)c->h_cnt->n_rays[d][sh].v;
+            ln += (uint64_t)c->h_cnt->n_nodes[d][sh].v;
         }
+        rays += lr; nodes += ln;
+        stats->level_rays[d] += lr; stats->level_nodes[d] += ln;
     }
     uint64_t shadow = nodes * (uint64_t)c->sc.n_lights;
     uint64_t q = rays + shadow;
@@ -1468,6 +1477,10 @@ extern "C" int t3d_render_rows_device(t3d_ctx* c, const t3d_opts* o, int row0, i
                 for (int k = 0; k < T3D_STATS_N_COUNTERS; ++k) dst[k] += src[k];
                 stats->ms_device += band_stats.ms_device; stats->ms_k_level += band_stats.ms_k_level;
                 stats->ms_resolve += band_stats.ms_resolve;
+                for (int k = 0; k < T3D_STATS_MAX_LEVELS; ++k) {
+                    stats->level_rays[k] += band_stats.level_rays[k]; stats->level_nodes[k] += band_stats.level_nodes[k];
+                    stats->level_ms[k] += band_stats.level_ms[k];
+                }
             }
             break;
         }

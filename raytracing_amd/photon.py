@@ -410,7 +410,10 @@ class Photon:
             out = ctx.render_rows(native_opts, seed=seed, row0=sid * stripe_rows, nrows=stripe_rows)
             image[sid * stripe_rows:(sid + 1) * stripe_rows] = out["bgr"]
             for k, v in out["stats"].items():
-                totals[k] = totals.get(k, 0) + v
+                if isinstance(v, list):      # per-level arrays
+                    totals[k] = [a + b for a, b in zip(totals.get(k, [0] * len(v)), v)]
+                else:
+                    totals[k] = totals.get(k, 0) + v
             progress[sid] = stripe_rows * width - 1
             if cancelCallback():
                 failed = True
