@@ -629,7 +629,7 @@ __device__ __forceinline__ void process_ray(const DevScene& sc, const DevSphere*
                 int nobj = obj;
                 if (obj == in.inside_obj) { Nn = N * -1.0f; n2 = 1.0f; nobj = -1; }
                 float cosI = -dot(d, Nn);
-                float ratio = in.ior / n2;
+                float ratio = in.ior * __builtin_amdgcn_rcpf(n2);
                 float sin2T = ratio * ratio * (1.0f - cosI * cosI);
                 if (!(sin2T > 1.0f)) {
                     float cosT = __builtin_amdgcn_sqrtf(1.0f - sin2T);
@@ -789,6 +789,7 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_level(DevScene sc, GEO_PARAMS, Re
     int ring_nodes = 0;  // nodes appended to the ring so far      (wave-uniform)
     int items_done = 0;  // (node, light) pairs already traced     (wave-uniform)
     BvhCount bc{0, 0, 0};
+    const float inv_L = 1.0f / (float)(L > 0 ? L : 1);
     for (;;) {
         const int pending = ring_nodes * L - items_done;
         const bool more = (long long)chunk * 128 < n_in;
@@ -796,9 +797,13 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_level(DevScene sc, GEO_PARAMS, Re
             // ---------------- shadow round: pairs items_done + lane and items_done + 64 + lane ----------------
             const int item0 = items_done + wc.lane, item1 = item0 + 64;
             const bool run0 = item0 < ring_nodes * L, run1 = item1 < ring_nodes * L;
-            const int it0 = run0 ? item0 : items_done, it1 = run1 ? item1 : items_done;
-            const int nd0 = it0 / L, nd1 = it1 / L;
-            const int l0 = it0 - nd0 * L, l1 = it1 - nd1 * L;
+            // item = node * L + light.  items_done is wave-uniform, so its quotient and remainder by L are scalar
+            // work; per lane only a small offset (< L + 128) is divided, exactly, in float.
+            const int nd_base = __builtin_amdgcn_readfirstlane(items_done / L), l_base = __builtin_amdgcn_readfirstlane(items_done % L);
+            const int x0 = l_base + (run0 ? wc.lane : 0), x1 = l_base + (run1 ? wc.lane + 64 : 0);
+            const int q0 = (int)(((float)x0 + 0.5f) * inv_L), q1 = (int)(((float)x1 + 0.5f) * inv_L);
+            const int nd0 = nd_base + q0, nd1 = nd_base + q1;
+            const int l0 = x0 - q0 * L, l1 = x1 - q1 * L;
             const float4 rb0 = ring_b[nd0 % T3D_RING], rb1 = ring_b[nd1 % T3D_RING];
             const ShadowRay s0 = shadow_ray(sc, ring_a[nd0 % T3D_RING], rb0, l0);
             const ShadowRay s1 = shadow_ray(sc, ring_a[nd1 % T3D_RING], rb1, l1);
