@@ -133,12 +133,11 @@ struct RayRec {
     uint4 k;   // x = pixel-sample index, y = sample << 16 | heap index, z = side (0 = reflected slot, 1 = transmitted), w = pixel hash of the random-number key
 };
 
-// Node arrays (structure of float4 arrays, 64 B per node in total)
+// Node arrays (36 B per node; hit point and normal of a node only live in the wave's LDS ring)
 struct NodePool {
-    float4* a;  // P.xyz, attenuation towards the parent
-    float4* b;  // unit normal, w = int bits: shader | side << 30
-    float4* c;  // reflected slot rgb (child colour * attenuation), w = int bits: parent index
-    float4* d;  // transmitted slot rgb
+    float4* c;    // reflected slot rgb (child colour * attenuation), w = this node's attenuation towards its parent
+    float4* d;    // transmitted slot rgb, w = int bits: shader | side << 30
+    int* parent;  // index of the parent node (level 0: of the primary sample)
     int* dbg;   // debug record index of the node (only in single-pixel mode)
     float* li;  // [levels * cap * L] direct-light intensity per (node, light), written by k_level
 };
@@ -604,9 +603,7 @@ __device__ __forceinline__ void process_ray(const DevScene& sc, const DevSphere*
             out.sample_color[in.i] = make_float4(c.x, c.y, c.z, 0.0f);
         } else if (hit) {
             float4* slot = in.side ? pool.d : pool.c;
-            float4 cur = slot[in.parent];
-            cur.x = emit.x * att_parent; cur.y = emit.y * att_parent; cur.z = emit.z * att_parent;
-            slot[in.parent] = cur;
+            *(float3*)&slot[in.parent] = make_float3(emit.x * att_parent, emit.y * att_parent, emit.z * att_parent);
         }
     }
 
@@ -676,10 +673,9 @@ __device__ __forceinline__ void process_ray(const DevScene& sc, const DevSphere*
     if (stored) {
         const float k = 2.0f / 255.0f;  // absent children count as ambient * 2/255 (T3DR.py:1054-1055)
         const size_t g = wc.node_base + (size_t)node;
-        pool.a[g] = make_float4(P.x, P.y, P.z, att_parent);
-        pool.b[g] = make_float4(N.x, N.y, N.z, __int_as_float(shader | (in.side << 30)));
-        pool.c[g] = make_float4(rp.ambient[0] * k, rp.ambient[1] * k, rp.ambient[2] * k, __int_as_float(in.parent));
-        pool.d[g] = make_float4(rp.ambient[0] * k, rp.ambient[1] * k, rp.ambient[2] * k, 0.0f);
+        pool.c[g] = make_float4(rp.ambient[0] * k, rp.ambient[1] * k, rp.ambient[2] * k, att_parent);
+        pool.d[g] = make_float4(rp.ambient[0] * k, rp.ambient[1] * k, rp.ambient[2] * k, __int_as_float(shader | (in.side << 30)));
+        pool.parent[g] = in.parent;
         if (rp.want_debug) pool.dbg[g] = dbg_idx;
     }
     if (want_t && stored) {
@@ -871,10 +867,10 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_resolve(DevScene sc, RenderParams
     const int n = min(cnt->n_nodes[level][shard].v, shard_cap);
     for (int k = (gw / T3D_SHARDS) * 64 + lane; k < n; k += (nw / T3D_SHARDS) * 64) {
         const size_t g = node_base + (size_t)shard * shard_cap + (size_t)k;
-        float4 a = pool.a[g], b = pool.b[g], c = pool.c[g], d = pool.d[g];
-        int meta = __float_as_int(b.w);
-        int shader = meta & 0x3FFFFFFF, side = (meta >> 30) & 1;
-        int parent = __float_as_int(c.w);
+        const float4 c = pool.c[g], d = pool.d[g];
+        const int meta = __float_as_int(d.w);
+        const int shader = meta & 0x3FFFFFFF, side = (meta >> 30) & 1;
+        const int parent = pool.parent[g];
         DevShader sh = sc.shaders[shader];
         float refl = sh.refl, tf = 1.0f - refl, I = 0.0f;
         for (int l = 0; l < sc.n_lights; ++l) I += pool.li[g * sc.n_lights + l];  // light order, T3DR.py:894
@@ -895,11 +891,9 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_resolve(DevScene sc, RenderParams
         if (level == 0) {
             sample_color[parent] = make_float4(res[0], res[1], res[2], 0.0f);
         } else {
-            float att = a.w;
+            const float att = c.w;
             float4* slot = side ? pool.d : pool.c;
-            float4 cur = slot[parent];
-            cur.x = res[0] * att; cur.y = res[1] * att; cur.z = res[2] * att;
-            slot[parent] = cur;
+            *(float3*)&slot[parent] = make_float3(res[0] * att, res[1] * att, res[2] * att);
         }
     }
 }
@@ -1059,7 +1053,7 @@ static void free_scene(t3d_ctx* c) {
     c->has_scene = false;
 }
 static void free_work(t3d_ctx* c) {
-    hipFree(c->d_rays[0]); hipFree(c->d_rays[1]); hipFree(c->pool.a); hipFree(c->pool.b); hipFree(c->pool.c);
+    hipFree(c->d_rays[0]); hipFree(c->d_rays[1]); hipFree(c->pool.parent); hipFree(c->pool.c);
     hipFree(c->pool.d); hipFree(c->pool.dbg); hipFree(c->pool.li);
     c->d_rays[0] = c->d_rays[1] = nullptr; c->pool = NodePool{}; c->cap_alloc = 0; c->levels_alloc = 0;
 }
@@ -1277,8 +1271,7 @@ static int ensure_work(t3d_ctx* c, size_t cap, int levels, size_t n0, bool dbg) 
         size_t cap2 = cap, lv = (size_t)levels;
         HIPCHK(c, hipMalloc((void**)&c->d_rays[0], sizeof(RayRec) * cap2));
         HIPCHK(c, hipMalloc((void**)&c->d_rays[1], sizeof(RayRec) * cap2));
-        HIPCHK(c, hipMalloc((void**)&c->pool.a, sizeof(float4) * cap2 * lv));
-        HIPCHK(c, hipMalloc((void**)&c->pool.b, sizeof(float4) * cap2 * lv));
+        HIPCHK(c, hipMalloc((void**)&c->pool.parent, sizeof(int) * cap2 * lv));
         HIPCHK(c, hipMalloc((void**)&c->pool.c, sizeof(float4) * cap2 * lv));
         HIPCHK(c, hipMalloc((void**)&c->pool.d, sizeof(float4) * cap2 * lv));
         if (dbg) HIPCHK(c, hipMalloc((void**)&c->pool.dbg, sizeof(int) * cap2 * lv));
@@ -1453,7 +1446,7 @@ extern "C" int t3d_render_rows_device(t3d_ctx* c, const t3d_opts* o, int row0, i
     const int S = o->bounces > 1 ? o->samples : 1;
     const int levels = o->bounces + 1;
     // rows per band: the optimistic working set (capacity factor 2 per level) must fit the budget
-    const size_t per_sample = (size_t)2 * (2 * sizeof(RayRec) + (size_t)levels * 64) + sizeof(float4);
+    const size_t per_sample = (size_t)2 * (2 * sizeof(RayRec) + (size_t)levels * (36 + 4 * (size_t)(c->sc.n_lights > 0 ? c->sc.n_lights : 1))) + sizeof(float4);
     size_t max_samples = c->mem_budget / per_sample;
     size_t max_idx = (size_t)0x7FFFFFF0 / ((size_t)levels * 2);
     if (max_samples > max_idx) max_samples = max_idx;
