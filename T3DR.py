@@ -1,8 +1,9 @@
 """Drop-in module name for scripts written against the reference renderers: ``from T3DR import Photon``.
 ``Photon`` / ``Rendered`` live in ``raytracing_amd.photon``.  The rasteriser preview (``Texel``), the
-orthographic debug viewer (``Debug``) and the post filters (``Post``) of the reference are not part of
-this build; the names exist so that scripts which merely construct them keep importing."""
+orthographic debug viewer (``Debug``) of the reference are not part of this build; the names exist so that
+scripts which merely construct them keep importing.  ``Post`` (image helpers) is in ``raytracing_amd.post``."""
 from raytracing_amd.photon import NoBoundCameraError, Photon, Rendered, ThreadsProgress  # noqa: F401
+from raytracing_amd.post import Post  # noqa: F401
 
 
 class _NotBuilt:
@@ -24,6 +25,3 @@ class Debug(_NotBuilt):
 class Texel(_NotBuilt):
     _what = "rasteriser preview"
 
-
-class Post(_NotBuilt):
-    _what = "post-processing filter set"

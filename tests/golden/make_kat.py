@@ -239,6 +239,21 @@ def main(ref):
         random.seed(seed)
         kat["mt_uniform"].append(dict(seed=seed, values=[random.uniform(-1, 1) for _ in range(8)]))
 
+    # Post filters (T3DR.py:1550-1647) on a small fixed image
+    import numpy as np
+    rng = np.random.default_rng(2024)
+    img = rng.integers(0, 256, (7, 9, 3))
+    img[2, 2:7] = img[2, 2]                      # a run of equal pixels
+    img[4, 1:5] = img[4, 1] + np.array([[3, -2, 1]])  # a run within the default tolerance
+    img = np.clip(img, 0, 255)
+    as_list = img.tolist()
+    comp = T3DR.Post.compressRenderedDict({"imgData": as_list, "width": 9, "height": 7}, tolerance=10)
+    comp0 = T3DR.Post.compressRenderedDict({"imgData": as_list, "width": 9, "height": 7}, tolerance=0)
+    kat["post"] = dict(image=as_list, compressed_tol10=comp["imgData"], compressed_tol0=comp0["imgData"],
+                       decompressed_tol10=T3DR.Post.decompressRenderedDict(comp)["imgData"],
+                       upscaled_x2=T3DR.Post.upscale(img.astype(np.uint8), 2).tolist(),
+                       denoised_k3=[[list(map(int, px)) for px in row] for row in T3DR.Post.denoise(as_list, 3)])
+
     with open(os.path.join(HERE, "kat.json"), "w") as f:
         json.dump(kat, f)
     print({k: len(val) for k, val in kat.items()})

@@ -154,3 +154,39 @@ def test_synthetic_flat_equals_flattened_object_graph():
     for f in dataclasses.fields(a):
         x, y = np.asarray(getattr(a, f.name)), np.asarray(getattr(b, f.name))
         assert x.dtype == y.dtype and np.array_equal(x, y), f.name
+
+
+def test_post_filters_match_reference_known_answers(kat):
+    """Post.compress / decompress / upscale / denoise against outputs of the reference (tests/golden/make_kat.py)."""
+    import T3DR
+    k = kat["post"]
+    img = k["image"]
+    base = {"imgData": img, "width": 9, "height": 7, "rays": 5}
+    c10 = T3DR.Post.compressRenderedDict(base, tolerance=10)
+    assert c10["imgData"] == k["compressed_tol10"] and c10["rays"] == 5 and base["imgData"] is img
+    assert T3DR.Post.compressRenderedDict(base, tolerance=0)["imgData"] == k["compressed_tol0"]
+    assert T3DR.Post.decompressRenderedDict(c10)["imgData"] == k["decompressed_tol10"]
+    up = T3DR.Post.upscale(np.array(img, np.uint8), 2)
+    assert up.dtype == np.uint8 and up.tolist() == k["upscaled_x2"]
+    den = T3DR.Post.denoise(img, 3)
+    assert [[list(px) for px in row] for row in den] == k["denoised_k3"] and isinstance(den[0][0], tuple)
+    # lossless round trip at tolerance 0
+    assert T3DR.Post.decompressRenderedDict(T3DR.Post.compressRenderedDict(base, tolerance=0))["imgData"] == img
+
+
+def test_rendered_json_round_trip(tmp_path):
+    """Rendered.saveJSON / fromJSON (T3DR.py:59-118) and every imageAs form, without a device."""
+    import T3DR
+    rng = np.random.default_rng(1)
+    bgr = rng.integers(0, 256, (4, 6, 3)).astype(np.uint8)
+    r = T3DR.Rendered(bgr, {}, 6, 4, time=0.25, rays=99, options={"bounces": 2, "ambient": RGB(1, 2, 3)}, engine="photon")
+    assert np.array_equal(r.imageAs("np"), bgr[:, :, ::-1]) and np.array_equal(r.imageAs("cv2"), bgr)
+    assert r.imageAs("tupleList")[1][2] == tuple(int(c) for c in bgr[1, 2, ::-1]) and r.imageAs("listList")[3][5] == bgr[3, 5, ::-1].tolist()
+    path = tmp_path / "render.json"
+    r.saveJSON(str(path))
+    back = T3DR.Rendered.fromJSON(str(path))
+    assert np.array_equal(back.imageAs("np"), r.imageAs("np")) and (back.width, back.height, back.rays, back.time) == (6, 4, 99, 0.25)
+    assert back.engine == "photon" and [*back.options["ambient"]] == [1, 2, 3] and back.options["bounces"] == 2
+    # the compressed form survives the same path
+    packed = T3DR.Post.compressRenderedDict(r.toDict(), tolerance=0)
+    assert np.array_equal(T3DR.Rendered.fromDict(T3DR.Post.decompressRenderedDict(packed)).imageAs("np"), r.imageAs("np"))
