@@ -80,8 +80,9 @@ struct DevCamera {
 
 // Geometry streamed by every closest-hit query; passed as separate __restrict__ kernel arguments so
 // that the compiler may use scalar loads for it.
-//   planes      [G]   (n.x, -n.v0, n.y, n.z) of the first triangle of each coplanar group, un-normalised like
-//                     MathematicalPlane.normal (T3DE.py:251-263)
+//   planes      [6G]  per coplanar group a 96-byte record: (n.x, -n.v0, n.y, n.z) of its first triangle, un-normalised
+//                     like MathematicalPlane.normal (T3DE.py:251-263); (first, end) of its triangle range as int
+//                     bits; the tri_uv rows of its first two triangles (zeros where the group has only one)
 //   plane_first [G+1] triangle range of each group
 //   tri_uv      [2T]  per triangle (a_s, aw, a_t, 0), (b_s, bw, b_t, 0): barycentric rows in the two in-plane
 //                     coordinates (s, t) left after dropping the group's dominant axis, prepared in float64
@@ -246,7 +247,10 @@ __device__ __forceinline__ void plane_groups(const float4* __restrict__ planes, 
     const f2 os = AX == 0 ? oy : (AX == 1 ? oz : ox), ot = AX == 0 ? oz : (AX == 1 ? ox : oy);
     const f2 ds = AX == 0 ? dy : (AX == 1 ? dz : dx), dt = AX == 0 ? dz : (AX == 1 ? dx : dy);
     for (int g = g_begin; g < g_end; ++g) {
-        const float4 rn = planes[g];
+        // One 96-byte record per group: plane row, triangle range, and the rows of its first two triangles --
+        // requested together, so a group of up to two triangles costs a single wait on scalar memory.
+        const float4 rn = planes[6 * g], rk = planes[6 * g + 1];
+        const float4 fa0 = planes[6 * g + 2], fb0 = planes[6 * g + 3], fa1 = planes[6 * g + 4], fb1 = planes[6 * g + 5];
         const f2 dn = fma2(splat(rn.w), dz, fma2(splat(rn.z), dy, splat(rn.x) * dx));
         const f2 q = fma2(splat(rn.w), oz, fma2(splat(rn.z), oy, fma2(splat(rn.x), ox, splat(rn.y))));  // n.o - n.v0
         const f2 e = fma2(dn, dn, splat(-1e-12f));
@@ -257,9 +261,8 @@ __device__ __forceinline__ void plane_groups(const float4* __restrict__ planes, 
         const f2 t = -q * inv;
         const uint32_t tp0 = __float_as_uint(t.x), tp1 = __float_as_uint(t.y);
         if (!__any((tp0 < best0) | (tp1 < best1))) continue;  // wave-uniform
-        const int k0 = plane_first[g], k1 = plane_first[g + 1];
+        const int k0 = __float_as_int(rk.x), k1 = __float_as_int(rk.y);
         const f2 ps = fma2(ds, t, os), pt = fma2(dt, t, ot);
-        f2 A = splat(0.0f);
         auto inside = [&](float4 ra, float4 rb) -> f2 {
             const f2 u = fma2(splat(ra.z), pt, fma2(splat(ra.x), ps, splat(ra.y)));
             const f2 v = fma2(splat(rb.z), pt, fma2(splat(rb.x), ps, splat(rb.y)));
@@ -267,9 +270,10 @@ __device__ __forceinline__ void plane_groups(const float4* __restrict__ planes, 
             const f2 m = {fminf(fminf(u.x, v.x), w.x), fminf(fminf(u.y, v.y), w.y)};
             return step01(m, big);
         };
-        // two triangles per step: both row pairs are requested before either is used (one scalar-load wait
-        // per two triangles, and two independent dependency chains for the scheduler)
-        int k = k0;
+        // two triangles per step; the first step always covers two bit positions (a group of one triangle has
+        // an all-zero second row pair, which is never inside)
+        f2 A = fma2(inside(fa0, fb0), splat(2.0f), inside(fa1, fb1));
+        int k = k0 + 2;
         for (; k + 1 < k1; k += 2) {
             const float4 ra0 = tri_uv[2 * k + 0], rb0 = tri_uv[2 * k + 1], ra1 = tri_uv[2 * k + 2], rb1 = tri_uv[2 * k + 3];
             const f2 f0 = inside(ra0, rb0), f1 = inside(ra1, rb1);
@@ -287,7 +291,8 @@ __device__ __forceinline__ void plane_groups(const float4* __restrict__ planes, 
 // Triangle index from the hit bits of its group: bit (n-1-j) stands for the j-th triangle of the group.
 __device__ __forceinline__ int first_hit_of_group(const int* __restrict__ plane_first, int g, float A) {
     const int k0 = plane_first[g], n = plane_first[g + 1] - k0;
-    int j = n - 1 - ((int)(__float_as_uint(A) >> 23) - 127);
+    const int width = n > 2 ? n : 2;  // bit positions used by the group: the first step always takes two
+    int j = width - 1 - ((int)(__float_as_uint(A) >> 23) - 127);
     j = j < 0 ? 0 : (j > n - 1 ? n - 1 : j);
     return k0 + j;
 }
@@ -1162,7 +1167,7 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
         }
     }
     const size_t G = pieces.size();
-    std::vector<float4> planes(G + 1, make_float4(0.f, 0.f, 0.f, 0.f));
+    std::vector<float4> planes(6 * (G + 1), make_float4(0.f, 0.f, 0.f, 0.f));
     std::vector<int> plane_first(G + 1, 0);
     std::vector<float4> tri_uv((size_t)2 * (s->n_tris + 1), make_float4(0.f, 0.f, 0.f, 0.f));
     std::vector<float4> tri_n((size_t)s->n_tris + 1, make_float4(0.f, 0.f, 0.f, 0.f));
@@ -1175,7 +1180,8 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
             const Tri& F = tris[groups[pc.group][0]];
             // rows are stored (x, offset, y, z): the first fma of a dot product then takes its factor and its
             // addend from one aligned SGPR pair; "+ 0.0f" turns a -0 offset into +0
-            planes[g] = make_float4((float)F.n[0], -(float)F.nv0 + 0.0f, (float)F.n[1], (float)F.n[2]);
+            planes[6 * g] = make_float4((float)F.n[0], -(float)F.nv0 + 0.0f, (float)F.n[1], (float)F.n[2]);
+            planes[6 * g + 1] = make_float4(__builtin_bit_cast(float, k), __builtin_bit_cast(float, k + pc.count), 0.f, 0.f);
             plane_first[g] = k;
             const int i1 = (pc.axis + 1) % 3, i2 = (pc.axis + 2) % 3;  // in-plane coordinates (s, t)
             for (int j = 0; j < pc.count; ++j) {
@@ -1191,6 +1197,7 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
                     tri_uv[2 * (size_t)k + 0] = make_float4((float)as, (float)aw + 0.0f, (float)at, 0.f);
                     tri_uv[2 * (size_t)k + 1] = make_float4((float)bs, (float)bw + 0.0f, (float)bt, 0.f);
                 }   // else: degenerate triangle, rows stay zero and min3(u, v, w) = 0 never counts as inside
+                if (j < 2) { planes[6 * g + 2 + 2 * j] = tri_uv[2 * (size_t)k + 0]; planes[6 * g + 3 + 2 * j] = tri_uv[2 * (size_t)k + 1]; }
                 tri_n[k] = make_float4((float)T.n[0], (float)T.n[1], (float)T.n[2], -(float)T.nv0 + 0.0f);
                 order[k] = t;
                 meta[k] = make_int4(T.obj, T.face, T.shader, t);
