@@ -58,20 +58,39 @@ def assemble(tiles, height: int, mode: str = "interleaved"):
     return frame
 
 
+_workspace = {}   # receive buffer and frame of the last gather shape (rank dst only)
+
+
 def gather_frame(tile, height: int, mode: str = "interleaved", group=None, dst: int = 0):
     """Collect every rank's tile on rank ``dst`` and return the assembled frame there (``None`` on
     the other ranks).  ``tile`` is a torch tensor [H/G, W, C] on the device the backend moves
-    (GPU for nccl/RCCL, CPU for gloo).  Single-process use returns the tile's own frame."""
+    (GPU for nccl/RCCL, CPU for gloo).  Single-process use returns the tile's own frame.  The returned
+    frame is a buffer that the next call with the same shapes overwrites."""
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return assemble([tile], height, mode)
+        return tile if tile.shape[0] == height else assemble([tile], height, mode)   # one rank: the tile is the frame
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     tile = tile.contiguous()
     if rank == dst:
-        parts = [tile.new_empty(tile.shape) for _ in range(world)]
-        dist.gather(tile, parts, dst=dst, group=group)
-        return assemble(parts, height, mode)
+        # one receive buffer [G, H/G, W, C] and one frame, kept between calls; the tiles land in the buffer
+        # and a single strided copy puts the rows in place
+        key = (tuple(tile.shape), tile.dtype, tile.device, world, height)
+        ws = _workspace.get(key)
+        if ws is None:
+            _workspace.clear()
+            ws = (tile.new_empty((world,) + tuple(tile.shape)), tile.new_empty((height,) + tuple(tile.shape[1:])))
+            _workspace[key] = ws
+        stacked, frame = ws
+        dist.gather(tile, [stacked[r] for r in range(world)], dst=dst, group=group)
+        n = height // world
+        if mode == "bands":
+            frame.view((world, n) + tuple(tile.shape[1:])).copy_(stacked)
+        elif mode == "interleaved":
+            frame.view((n, world) + tuple(tile.shape[1:])).copy_(stacked.transpose(0, 1))
+        else:
+            raise ValueError(f"unknown partition mode {mode!r}")
+        return frame
     dist.gather(tile, None, dst=dst, group=group)
     return None
 
