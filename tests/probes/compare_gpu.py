@@ -2,7 +2,7 @@
 """Developer probe: render every golden case on the GPU and print how it differs from the CPU oracle."""
 import glob, json, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from raytracing_amd.scene import Scene
 from raytracing_amd.flatten import flatten_scene
