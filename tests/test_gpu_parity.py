@@ -279,3 +279,28 @@ def test_photon_trace_compute_color_direct_light(gpu_ctx):
     inside = T3DE.Ray(mid, T3DE.Vec3(0.3, 0.2, 1).normalise(), cube.material.ior, cube)
     tree = photon.trace(inside, 1, lights=True)
     assert tree is not None and tree.collisionInfo["object"].id == cube.id and tree.collisionInfo["direction"] == 1
+
+
+def test_bench_line_contract():
+    """bench.py prints one JSON line with the fields the driver reads, a roofline and a CPU baseline."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-row-step", "90"],
+                         capture_output=True, text=True, timeout=200, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "Mrays/s" and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert d["config"]["workload"] == "cornell_1080p_b4" and d["config"]["width"] == 1920 and d["config"]["bounces"] == 4
+    r = d["roofline"]
+    assert r["bound"] == "valu" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1
+    assert abs(d["value"] - d["config"]["queries_per_frame"] / d["ms_per_step"] / 1e3) < 0.01 * d["value"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "rows" in c["sample"]
