@@ -280,11 +280,10 @@ __device__ __forceinline__ void plane_groups(const float4* __restrict__ planes, 
             A = fma2(A, splat(4.0f), fma2(f0, splat(2.0f), f1));
         }
         if (k < k1) A = fma2(A, splat(2.0f), inside(tri_uv[2 * k + 0], tri_uv[2 * k + 1]));
-        const uint32_t tt0 = (A.x >= 1.0f) ? tp0 : 0x7f800000u;
-        const uint32_t tt1 = (A.y >= 1.0f) ? tp1 : 0x7f800000u;
-        const bool cl0 = tt0 < best0, cl1 = tt1 < best1;
-        best0 = cl0 ? tt0 : best0; A0 = cl0 ? A.x : A0; bg0 = cl0 ? g : bg0;
-        best1 = cl1 ? tt1 : best1; A1 = cl1 ? A.y : A1; bg1 = cl1 ? g : bg1;
+        // closer = some triangle of the group was hit AND the plane is nearer (two compares and a scalar AND)
+        const bool cl0 = (A.x >= 1.0f) & (tp0 < best0), cl1 = (A.y >= 1.0f) & (tp1 < best1);
+        best0 = cl0 ? tp0 : best0; A0 = cl0 ? A.x : A0; bg0 = cl0 ? g : bg0;
+        best1 = cl1 ? tp1 : best1; A1 = cl1 ? A.y : A1; bg1 = cl1 ? g : bg1;
     }
 }
 
