@@ -82,7 +82,8 @@ struct DevCamera {
 // that the compiler may use scalar loads for it.
 //   planes      [6G]  per coplanar group a 96-byte record: (n.x, -n.v0, n.y, n.z) of its first triangle, un-normalised
 //                     like MathematicalPlane.normal (T3DE.py:251-263); (first, end) of its triangle range as int
-//                     bits; the tri_uv rows of its first two triangles (zeros where the group has only one)
+//                     bits and a parallelogram flag; the tri_uv rows of its first two triangles (zeros where the
+//                     group has only one; for a parallelogram only the first triangle's, see t3d_upload_scene)
 //   plane_first [G+1] triangle range of each group
 //   tri_uv      [2T]  per triangle (a_s, aw, a_t, 0), (b_s, bw, b_t, 0): barycentric rows in the two in-plane
 //                     coordinates (s, t) left after dropping the group's dominant axis, prepared in float64
@@ -272,7 +273,18 @@ __device__ __forceinline__ void plane_groups(const float4* __restrict__ planes, 
         };
         // two triangles per step; the first step always covers two bit positions (a group of one triangle has
         // an all-zero second row pair, which is never inside)
-        f2 A = fma2(inside(fa0, fb0), splat(2.0f), inside(fa1, fb1));
+        f2 A;
+        if (__float_as_int(rk.z) != 0) {   // wave-uniform: the first two triangles form a parallelogram
+            const f2 u = fma2(splat(fa0.z), pt, fma2(splat(fa0.x), ps, splat(fa0.y)));
+            const f2 v = fma2(splat(fb0.z), pt, fma2(splat(fb0.x), ps, splat(fb0.y)));
+            const f2 w = (splat(1.0f) - u) - v;
+            const f2 u1 = splat(1.0f) - u, v1 = splat(1.0f) - v;
+            const f2 ma = {fminf(fminf(u.x, v.x), w.x), fminf(fminf(u.y, v.y), w.y)};
+            const f2 mb = {fminf(fminf(u1.x, v1.x), -w.x), fminf(fminf(u1.y, v1.y), -w.y)};
+            A = fma2(step01(ma, big), splat(2.0f), step01(mb, big));
+        } else {
+            A = fma2(inside(fa0, fb0), splat(2.0f), inside(fa1, fb1));
+        }
         int k = k0 + 2;
         for (; k + 1 < k1; k += 2) {
             const float4 ra0 = tri_uv[2 * k + 0], rb0 = tri_uv[2 * k + 1], ra1 = tri_uv[2 * k + 2], rb1 = tri_uv[2 * k + 3];
@@ -1204,6 +1216,41 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
             }
         }
         plane_first[G] = k;
+        // Parallelograms: when the first two triangles of a group share an edge and their other two corners are
+        // opposite corners of a parallelogram, the second triangle's barycentrics are the mirror image of the
+        // first one's (u' = 1 - u, v' = 1 - v, w' = -w, origin at the corner opposite the shared edge), and the
+        // kernel derives both interior tests from one (u, v).  The record then holds the first triangle's rows
+        // with that origin and a flag.
+        for (size_t g = 0; g < G; ++g) {
+            const Piece& pc = pieces[g];
+            if (pc.count < 2) continue;
+            const double* A = s->tri_verts + 9 * (size_t)groups[pc.group][pc.first];
+            const double* B = s->tri_verts + 9 * (size_t)groups[pc.group][pc.first + 1];
+            int shared_a = 0, shared_b = 0, n_shared = 0;   // bit masks of the corners that coincide exactly
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j)
+                    if (A[3 * i] == B[3 * j] && A[3 * i + 1] == B[3 * j + 1] && A[3 * i + 2] == B[3 * j + 2]) { shared_a |= 1 << i; shared_b |= 1 << j; ++n_shared; }
+            if (n_shared != 2 || __builtin_popcount(shared_a) != 2 || __builtin_popcount(shared_b) != 2) continue;
+            const int ia = shared_a == 6 ? 0 : (shared_a == 5 ? 1 : 2), ib = shared_b == 6 ? 0 : (shared_b == 5 ? 1 : 2);  // the lone corners
+            const int i1a = (ia + 1) % 3, i2a = (ia + 2) % 3;
+            double scale = 0, err = 0;
+            for (int c3 = 0; c3 < 3; ++c3) {
+                const double sum_diag = A[3 * i1a + c3] + A[3 * i2a + c3], sum_lone = A[3 * ia + c3] + B[3 * ib + c3];
+                err = fmax(err, fabs(sum_diag - sum_lone));
+                scale = fmax(scale, fmax(fabs(sum_diag), fabs(A[3 * i1a + c3] - A[3 * i2a + c3])));
+            }
+            if (!(err <= 1e-10 * scale)) continue;
+            const int i1 = (pc.axis + 1) % 3, i2 = (pc.axis + 2) % 3;
+            const double* v0 = A + 3 * ia; const double* v1 = A + 3 * i1a; const double* v2 = A + 3 * i2a;
+            const double e1s = v1[i1] - v0[i1], e1t = v1[i2] - v0[i2], e2s = v2[i1] - v0[i1], e2t = v2[i2] - v0[i2];
+            const double det = e1s * e2t - e2s * e1t;
+            if (det == 0.0) continue;
+            const double as = e2t / det, at = -e2s / det, bs = -e1t / det, bt = e1s / det;
+            const double aw = -(as * v0[i1] + at * v0[i2]), bw = -(bs * v0[i1] + bt * v0[i2]);
+            planes[6 * g + 2] = make_float4((float)as, (float)aw + 0.0f, (float)at, 0.f);
+            planes[6 * g + 3] = make_float4((float)bs, (float)bw + 0.0f, (float)bt, 0.f);
+            planes[6 * g + 1].z = __builtin_bit_cast(float, 1);
+        }
     }
     std::vector<DevShader> shaders((size_t)s->n_shaders);
     for (int k = 0; k < s->n_shaders; ++k) {
