@@ -304,3 +304,52 @@ def test_bench_line_contract():
     assert abs(d["value"] - d["config"]["queries_per_frame"] / d["ms_per_step"] / 1e3) < 0.01 * d["value"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "rows" in c["sample"]
+
+
+def test_plane_group_corner_cases(gpu_ctx, oracle_mod):
+    """One plane of 60 triangles (cut into pieces of 24), a duplicated triangle with another shader (the first one
+    tested must win), a degenerate triangle, a lone triangle, parallelograms and non-parallelogram pairs."""
+    from raytracing_amd.flatten import flatten_scene
+    from raytracing_amd.scene import RGB, Camera, Light, Mesh, Object, Scene, Shader, Vec3
+    s = Scene()
+    verts, faces = [], []
+
+    def tri(a, b, c):
+        base = len(verts)
+        verts.extend([Vec3(*a), Vec3(*b), Vec3(*c)])
+        faces.append((base, base + 1, base + 2))
+
+    # floor: 5 x 6 cells, two triangles each, all in the plane y = -1
+    for i in range(5):
+        for j in range(6):
+            x0, x1, z0, z1 = -2.5 + i, -1.5 + i, 2.0 + j, 3.0 + j
+            tri((x0, -1, z0), (x0, -1, z1), (x1, -1, z0))
+            tri((x1, -1, z0), (x0, -1, z1), (x1, -1, z1))
+    # back wall: a trapezoid split in two (not a parallelogram) and a lone triangle in its own plane
+    tri((-2.5, -1, 8), (2.5, -1, 8), (-1.5, 2, 8))
+    tri((2.5, -1, 8), (1.0, 2, 8), (-1.5, 2, 8))
+    tri((-2.5, -1, 7.5), (-2.5, 2, 6.0), (-2.5, -1, 4.0))
+    # a small raised triangle, then the same triangle again (second copy must never be reported), then a degenerate one
+    tri((-0.5, -0.5, 4), (0.0, -0.5, 5), (0.5, -0.5, 4))
+    tri((-0.5, -0.5, 4), (0.0, -0.5, 5), (0.5, -0.5, 4))
+    tri((1, 0, 5), (1, 0, 5), (2, 0, 5))
+    obj = Object(scene=s, name="planes", mesh=Mesh(verts, faces))
+    n = len(faces)
+    red, blue = Shader(color=RGB(220, 40, 40), roughness=0.8, reflectivity=0.7), Shader(color=RGB(40, 40, 220), roughness=0.2)
+    obj.setShader(Shader(color=RGB(180, 180, 180), roughness=1.0, reflectivity=0.9), list(range(n)))
+    obj.setShader(red, [n - 3])
+    obj.setShader(blue, [n - 2])
+    Light(s, position=Vec3(0.3, 3, 4.5), strength=1.2)
+    Camera(s, position=Vec3(0.113, 0.657, -1.9))
+    flat = flatten_scene(s)
+    gpu_ctx.set_accel("brute")
+    gpu_ctx.upload(flat)
+    for opt in (dict(width=120, height=90, bounces=0), dict(width=120, height=90, bounces=3, samples=2)):
+        out = gpu_ctx.render_rows(opt, seed=9, want_radiance=True, want_primary=True)
+        ref = oracle_mod.render(flat, opt, seed=9)
+        frag = oracle_mod.primary_fragility(flat, opt)
+        check_against_oracle(out, ref, frag)
+        hit_dup = (out["prim"][..., 1] == n - 3).sum()
+        assert hit_dup > 10 and (out["prim"][..., 1] == n - 2).sum() == 0 and (out["prim"][..., 1] == n - 1).sum() == 0
+        assert len(np.unique(out["prim"][..., 1])) > 40       # most floor triangles are seen
+    gpu_ctx.set_accel("auto")
