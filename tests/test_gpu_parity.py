@@ -353,3 +353,24 @@ def test_plane_group_corner_cases(gpu_ctx, oracle_mod):
         assert hit_dup > 10 and (out["prim"][..., 1] == n - 2).sum() == 0 and (out["prim"][..., 1] == n - 1).sum() == 0
         assert len(np.unique(out["prim"][..., 1])) > 40       # most floor triangles are seen
     gpu_ctx.set_accel("auto")
+
+
+def test_many_lights(gpu_ctx, oracle_mod):
+    """Twelve Light objects plus the emissive panel: many shadow rays per node through the per-wave ring."""
+    from raytracing_amd.flatten import flatten_scene
+    from raytracing_amd.scene import Light, Vec3
+    from raytracing_amd.workloads import cornell_scene
+    scene = cornell_scene(with_light=True)
+    rng = np.random.default_rng(3)
+    for i in range(11):
+        p = rng.uniform(-2.5, 2.5, 3)
+        Light(scene=scene, name=f"extra{i}", position=Vec3(float(p[0]), float(p[1]), float(1.0 + p[2])), strength=float(rng.uniform(0.1, 0.6)))
+    flat = flatten_scene(scene)
+    assert len(flat.light_strength) >= 13
+    gpu_ctx.set_accel("auto")
+    gpu_ctx.upload(flat)
+    opt = dict(width=100, height=60, bounces=3, samples=1, ambient=(32, 32, 32))
+    out = gpu_ctx.render_rows(opt, seed=2, want_radiance=True, want_primary=True)
+    ref = oracle_mod.render(flat, opt, seed=2)
+    check_against_oracle(out, ref, oracle_mod.primary_fragility(flat, opt))
+    assert out["stats"]["shadow_queries"] == len(flat.light_strength) * out["stats"]["nodes"]
