@@ -94,6 +94,7 @@ struct DevCamera {
 struct DevGeo {
     int axis_end[3];  // plane groups [0, axis_end[0]) have their largest normal component along x, then y, then z
     int n_tris, n_spheres;
+    float box_lo[3], box_hi[3];  // bounds of every triangle and sphere, padded outward
 };
 struct DevBvh {
     const float4* nodes;   // [n_prims - 1] x 4 rows, see t3d_lbvh.h; null when the scene is traced by brute force
@@ -308,11 +309,32 @@ __device__ __forceinline__ int first_hit_of_group(const int* __restrict__ plane_
     return k0 + j;
 }
 
+// BOX_FIRST (camera rays): when no ray of the wave meets the scene's bounding box, nothing is tested at all.  The
+// reference culls per object with padded boxes (T3DR.py:670-705); like there, the cull is conservative.
+template <bool BOX_FIRST = false>
 __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0, V3 d0, V3 o1, V3 d1,
                                              bool lights, bool back_cull0, bool back_cull1, Hit& out0, Hit& out1) {
     const uint32_t INF_BITS = 0x7f800000u;
     const f2 ox = {o0.x, o1.x}, oy = {o0.y, o1.y}, oz = {o0.z, o1.z};
     const f2 dx = {d0.x, d1.x}, dy = {d0.y, d1.y}, dz = {d0.z, d1.z};
+    if constexpr (BOX_FIRST) {
+        // slab test with 1/d clamped to a huge finite value (0 * inf would be NaN on a box face)
+        auto meets = [&](V3 o, V3 d) -> bool {
+            const float BIGF = 1e30f;
+            const float ix = fminf(fmaxf(__builtin_amdgcn_rcpf(d.x), -BIGF), BIGF), iy = fminf(fmaxf(__builtin_amdgcn_rcpf(d.y), -BIGF), BIGF),
+                        iz = fminf(fmaxf(__builtin_amdgcn_rcpf(d.z), -BIGF), BIGF);
+            const float ax = (geo.box_lo[0] - o.x) * ix, bx = (geo.box_hi[0] - o.x) * ix;
+            const float ay = (geo.box_lo[1] - o.y) * iy, by = (geo.box_hi[1] - o.y) * iy;
+            const float az = (geo.box_lo[2] - o.z) * iz, bz = (geo.box_hi[2] - o.z) * iz;
+            const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+            const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000004f;
+            return tn <= tf;
+        };
+        if (!__any((int)meets(o0, d0) | (int)meets(o1, d1))) {   // wave-uniform
+            out0.t = out1.t = __builtin_inff(); out0.prim = out1.prim = -1; out0.back = out1.back = 0;
+            return;
+        }
+    }
     const f2 cull = {back_cull0 ? 0.0f : __builtin_inff(), back_cull1 ? 0.0f : __builtin_inff()};
     const f2 big = splat(0x1p126f);
     uint32_t best0 = INF_BITS, best1 = INF_BITS;
@@ -841,7 +863,7 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_level(DevScene sc, GEO_PARAMS, Re
                 bvh_closest(sc, spheres, in0.o, in0.d, in0.active, lights, in0.ior == 1.0f, h0, bc, &cnt->bvh_stack_overflow);
                 bvh_closest(sc, spheres, in1.o, in1.d, in1.active, lights, in1.ior == 1.0f, h1, bc, &cnt->bvh_stack_overflow);
             } else {
-                closest_hit2(GEO_ARGS, sc.geo, in0.o, in0.d, in1.o, in1.d, lights, in0.ior == 1.0f, in1.ior == 1.0f, h0, h1);
+                closest_hit2<LEVEL0>(GEO_ARGS, sc.geo, in0.o, in0.d, in1.o, in1.d, lights, in0.ior == 1.0f, in1.ior == 1.0f, h0, h1);
             }
             process_ray<LEVEL0>(sc, spheres, rp, wc, in0, h0, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes);
             process_ray<LEVEL0>(sc, spheres, rp, wc, in1, h1, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes);
@@ -1300,6 +1322,19 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
     d.bvh.nodes = (const float4*)c->d_bvh_nodes; d.bvh.tri_ab = (const float4*)c->d_tri_ab; d.bvh.n_prims = n_prims;
     d.geo.axis_end[0] = axis_count[0]; d.geo.axis_end[1] = axis_count[0] + axis_count[1]; d.geo.axis_end[2] = (int)G;
     d.geo.n_tris = s->n_tris; d.geo.n_spheres = (int)spheres.size();
+    {   // scene bounds for the camera-ray pre-test, padded outward by 1e-4 of their size
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (size_t q = 0; q < (size_t)s->n_tris * 9; ++q) { lo[q % 3] = fmin(lo[q % 3], s->tri_verts[q]); hi[q % 3] = fmax(hi[q % 3], s->tri_verts[q]); }
+        for (const DevSphere& sp : spheres) {
+            const double r = sqrt((double)sp.r2) * 1.000001, cc[3] = {sp.cx, sp.cy, sp.cz};
+            for (int a = 0; a < 3; ++a) { lo[a] = fmin(lo[a], cc[a] - r); hi[a] = fmax(hi[a], cc[a] + r); }
+        }
+        for (int a = 0; a < 3; ++a) {
+            const double pad = 1e-4 * fmax(fmax(fabs(lo[a]), fabs(hi[a])), hi[a] - lo[a]) + 1e-30;
+            d.geo.box_lo[a] = lo[a] <= hi[a] ? (float)(lo[a] - pad) : 1.0f;   // no primitives: an empty box
+            d.geo.box_hi[a] = lo[a] <= hi[a] ? (float)(hi[a] + pad) : -1.0f;
+        }
+    }
     d.n_planes = (int)G; d.n_tris = s->n_tris; d.n_spheres = (int)spheres.size(); d.n_lights = s->n_lights; d.n_shaders = s->n_shaders;
     d.tri_n = (const float4*)c->d_tri_n; d.tri_meta = (const int4*)c->d_tri_meta;
     d.lights = (const DevLight*)c->d_lights; d.shaders = (const DevShader*)c->d_shaders; d.obj_ior = (const float*)c->d_obj_ior;
