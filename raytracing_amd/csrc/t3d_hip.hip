@@ -241,7 +241,7 @@ __device__ __forceinline__ f2 step01(f2 m, f2 big) {
 // The hit flags of a group (at most 24 triangles) are collected as the bits of an integer kept in a float:
 //     A = 2 A + step01(min3(u, v, w))
 // so its highest set bit is the FIRST triangle hit, which is the one the reference keeps (T3DR.py:715).
-template <int AX>
+template <int AX, bool NO_CULL>
 __device__ __forceinline__ void plane_groups(const float4* __restrict__ planes, const int* __restrict__ plane_first,
                                              const float4* __restrict__ tri_uv, int g_begin, int g_end, f2 ox, f2 oy, f2 oz,
                                              f2 dx, f2 dy, f2 dz, f2 cull, f2 big, uint32_t& best0, uint32_t& best1, float& A0,
@@ -256,8 +256,11 @@ __device__ __forceinline__ void plane_groups(const float4* __restrict__ planes, 
         const f2 dn = fma2(splat(rn.w), dz, fma2(splat(rn.z), dy, splat(rn.x) * dx));
         const f2 q = fma2(splat(rn.w), oz, fma2(splat(rn.z), oy, fma2(splat(rn.x), ox, splat(rn.y))));  // n.o - n.v0
         const f2 e = fma2(dn, dn, splat(-1e-12f));
-        const f2 c = cull - dn;
-        const f2 mn = {fminf(e.x, c.x), fminf(e.y, c.y)};
+        f2 mn = e;
+        if constexpr (!NO_CULL) {   // shadow rays count both sides of every face: no cull term for them
+            const f2 c = cull - dn;
+            mn = f2{fminf(e.x, c.x), fminf(e.y, c.y)};
+        }
         const f2 dnv = dn * step01(mn, big);
         const f2 inv = {__builtin_amdgcn_rcpf(dnv.x), __builtin_amdgcn_rcpf(dnv.y)};
         const f2 t = -q * inv;
@@ -311,7 +314,7 @@ __device__ __forceinline__ int first_hit_of_group(const int* __restrict__ plane_
 
 // BOX_FIRST (camera rays): when no ray of the wave meets the scene's bounding box, nothing is tested at all.  The
 // reference culls per object with padded boxes (T3DR.py:670-705); like there, the cull is conservative.
-template <bool BOX_FIRST = false>
+template <bool BOX_FIRST = false, bool NO_CULL = false>
 __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0, V3 d0, V3 o1, V3 d1,
                                              bool lights, bool back_cull0, bool back_cull1, Hit& out0, Hit& out1) {
     const uint32_t INF_BITS = 0x7f800000u;
@@ -340,9 +343,9 @@ __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0
     uint32_t best0 = INF_BITS, best1 = INF_BITS;
     float A0 = 0.0f, A1 = 0.0f;
     int bg0 = 0, bg1 = 0;
-    plane_groups<0>(planes, plane_first, tri_uv, 0, geo.axis_end[0], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1);
-    plane_groups<1>(planes, plane_first, tri_uv, geo.axis_end[0], geo.axis_end[1], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1);
-    plane_groups<2>(planes, plane_first, tri_uv, geo.axis_end[1], geo.axis_end[2], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1);
+    plane_groups<0, NO_CULL>(planes, plane_first, tri_uv, 0, geo.axis_end[0], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1);
+    plane_groups<1, NO_CULL>(planes, plane_first, tri_uv, geo.axis_end[0], geo.axis_end[1], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1);
+    plane_groups<2, NO_CULL>(planes, plane_first, tri_uv, geo.axis_end[1], geo.axis_end[2], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1);
     int prim0 = -1, prim1 = -1, back0 = 0, back1 = 0;
     if (best0 < INF_BITS) prim0 = first_hit_of_group(plane_first, bg0, A0);
     if (best1 < INF_BITS) prim1 = first_hit_of_group(plane_first, bg1, A1);
@@ -846,7 +849,7 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_level(DevScene sc, GEO_PARAMS, Re
                 bvh_closest(sc, spheres, s0.start, s0.Ld, run0, true, false, h0, bc, &cnt->bvh_stack_overflow);
                 bvh_closest(sc, spheres, s1.start, s1.Ld, run1, true, false, h1, bc, &cnt->bvh_stack_overflow);
             } else {
-                closest_hit2(GEO_ARGS, sc.geo, s0.start, s0.Ld, s1.start, s1.Ld, true, false, false, h0, h1);
+                closest_hit2<false, true>(GEO_ARGS, sc.geo, s0.start, s0.Ld, s1.start, s1.Ld, true, false, false, h0, h1);
             }
             const float I0 = shadow_intensity(sc, spheres, s0, h0), I1 = shadow_intensity(sc, spheres, s1, h1);
             if (run0) pool.li[(wc.node_base + (size_t)__float_as_int(rb0.w)) * L + l0] = I0;
