@@ -2,7 +2,7 @@
 """Headline benchmark: Mrays/s (closest-hit queries per second) and frame time, Cornell box 1920x1080,
 4 bounces, on N MI355X GPUs of one node.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 200 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -84,8 +84,8 @@ def cpu_baseline(flat, options, seed, row_step=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cornell_1080p_b4")
     ap.add_argument("--partition", default="interleaved", choices=["interleaved", "bands"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
