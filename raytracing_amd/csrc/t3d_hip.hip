@@ -821,15 +821,21 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_level(DevScene sc, GEO_PARAMS, Re
     // input: level 0 is the dense list of primary samples; deeper levels read this wave's shard of the queue
     const int n_in = LEVEL0 ? rp.n0 : min(cnt->n_rays[level][wc.shard].v, wc.shard_cap);
     const int queue_base = wc.shard * wc.shard_cap;
-    int chunk = LEVEL0 ? gw : gw / T3D_SHARDS;  // in units of 128 rays
+    int chunk = LEVEL0 ? gw : gw / T3D_SHARDS;  // in units of cs rays
     const int chunk_step = LEVEL0 ? nw : nw / T3D_SHARDS;
+    // Rays per trace round.  A launch with little work (a thin band of rows, one rank's share of a frame) is
+    // bound by the number of rounds one wave runs back to back -- a trace round and the shadow rounds of the
+    // nodes it creates -- not by throughput: such a launch is cut into more, smaller chunks (64 or 32 rays,
+    // one per lane) as long as every chunk still finds a resident wave (half of the grid is resident).
+    const int resident = chunk_step / 2;
+    const int cs = n_in > 64 * resident ? 128 : (n_in > 32 * resident ? 64 : 32);
     int ring_nodes = 0;  // nodes appended to the ring so far      (wave-uniform)
     int items_done = 0;  // (node, light) pairs already traced     (wave-uniform)
     BvhCount bc{0, 0, 0};
     const float inv_L = 1.0f / (float)(L > 0 ? L : 1);
     for (;;) {
         const int pending = ring_nodes * L - items_done;
-        const bool more = (long long)chunk * 128 < n_in;
+        const bool more = (long long)chunk * cs < n_in;
         if (pending >= 128 || (!more && pending > 0)) {
             // ---------------- shadow round: pairs items_done + lane and items_done + 64 + lane ----------------
             const int item0 = items_done + wc.lane, item1 = item0 + 64;
@@ -856,10 +862,10 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_level(DevScene sc, GEO_PARAMS, Re
             if (run1) pool.li[(wc.node_base + (size_t)__float_as_int(rb1.w)) * L + l1] = I1;
             items_done += pending < 128 ? pending : 128;
         } else if (more) {
-            // ---------------- trace round: rays chunk*128 + lane and chunk*128 + 64 + lane ----------------
+            // ---------------- trace round: rays chunk*cs + lane and (cs = 128) chunk*cs + 64 + lane ----------------
             RayIn in0, in1;
-            load_ray<LEVEL0>(sc, rp, rays_in, chunk * 128 + wc.lane, n_in, queue_base, in0);
-            load_ray<LEVEL0>(sc, rp, rays_in, chunk * 128 + 64 + wc.lane, n_in, queue_base, in1);
+            load_ray<LEVEL0>(sc, rp, rays_in, chunk * cs + wc.lane, wc.lane < cs ? n_in : 0, queue_base, in0);
+            load_ray<LEVEL0>(sc, rp, rays_in, chunk * cs + 64 + wc.lane, cs == 128 ? n_in : 0, queue_base, in1);
             const bool lights = LEVEL0 ? (rp.lights != 0) : true;
             Hit h0, h1;  // back faces culled iff ray.ior == 1 (T3DR.py:961)
             if constexpr (BVH) {
