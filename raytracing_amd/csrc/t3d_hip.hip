@@ -119,6 +119,7 @@ struct RenderParams {
     int bounces, samples, lights;
     uint32_t seed;
     float ambient[3];
+    int resident_waves;  // waves of k_level the device holds at once
     int n0;          // primary samples of this launch (rows * width * samples)
     int cap;         // capacity of one level's ray queue / node array (multiple of T3D_SHARDS * 64)
     int want_debug;  // record t3d_node entries (t3d_trace_pixel)
@@ -826,8 +827,9 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_level(DevScene sc, GEO_PARAMS, Re
     // Rays per trace round.  A launch with little work (a thin band of rows, one rank's share of a frame) is
     // bound by the number of rounds one wave runs back to back -- a trace round and the shadow rounds of the
     // nodes it creates -- not by throughput: such a launch is cut into more, smaller chunks (64 or 32 rays,
-    // one per lane) as long as every chunk still finds a resident wave (half of the grid is resident).
-    const int resident = chunk_step / 2;
+    // one per lane) as long as every chunk still finds a resident wave.
+    const int resident_all = nw < rp.resident_waves ? nw : rp.resident_waves;
+    const int resident = LEVEL0 ? resident_all : resident_all / T3D_SHARDS;
     const int cs = n_in > 64 * resident ? 128 : (n_in > 32 * resident ? 64 : 32);
     int ring_nodes = 0;  // nodes appended to the ring so far      (wave-uniform)
     int items_done = 0;  // (node, light) pairs already traced     (wave-uniform)
@@ -1467,6 +1469,7 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
     for (int k = 0; k < 3; ++k) rp.ambient[k] = (float)o->ambient[k];
     rp.cap = (int)c->cap_alloc;
     rp.n0 = (int)n0;
+    rp.resident_waves = c->n_sm * 16;   // 4 waves per SIMD at this kernel's register count
     if (single) {
         rp.single = single->single; rp.px0 = single->px0; rp.py0 = single->py0; rp.sample0 = single->sample0; rp.want_debug = 1;
         for (int k = 0; k < 3; ++k) { rp.ray_o[k] = single->ray_o[k]; rp.ray_d[k] = single->ray_d[k]; }
