@@ -409,8 +409,8 @@ __device__ __forceinline__ void bvh_closest(const DevScene& sc, const DevSphere*
     float best = __builtin_inff();
     int prim = -1, back = 0, rank = 0x7fffffff;
     int stack[T3D_BVH_STACK];
-    int sp = 0;
-    int node = 0;
+    int sp = 0, top = 0;   // top mirrors stack[sp - 1]: a pop uses it at once and only then fetches the entry below,
+    int node = 0;          // so the private-memory read is off the critical path
     for (;;) {
         if (node >= 0) {
             const float4 r0 = nodes[4 * (size_t)node + 0], r1 = nodes[4 * (size_t)node + 1];
@@ -431,7 +431,7 @@ __device__ __forceinline__ void bvh_closest(const DevScene& sc, const DevSphere*
             const int c0 = __float_as_int(r3.x), c1 = __float_as_int(r3.y);
             if (h0 & h1) {
                 const bool first0 = n0 <= n1;
-                if (sp < T3D_BVH_STACK) stack[sp++] = first0 ? c1 : c0; else *stack_overflow = 1;
+                if (sp < T3D_BVH_STACK) { top = first0 ? c1 : c0; stack[sp++] = top; } else *stack_overflow = 1;
                 node = first0 ? c0 : c1;
                 continue;
             }
@@ -480,7 +480,9 @@ __device__ __forceinline__ void bvh_closest(const DevScene& sc, const DevSphere*
             }
         }
         if (sp == 0) break;
-        node = stack[--sp];
+        node = top;
+        --sp;
+        top = stack[sp > 0 ? sp - 1 : 0];
     }
     out.t = best; out.prim = prim; out.back = back;
 }
