@@ -50,7 +50,8 @@
 #define T3D_MAX_LIGHTS 64
 #define T3D_MAX_BOUNCES 14 /* heap index of the deepest node must fit 16 bits of the RNG key */
 #define T3D_SHARDS 64      /* queue shards per level; every launch holds a multiple of 64 waves */
-#define T3D_RING 256       /* nodes per wave: < 128 pairs pending before a trace round, which adds <= 128 nodes */
+#define T3D_RING 256       /* nodes per wave in the brute-force kernels: < 128 pairs pending before a trace round, which adds <= 128 nodes */
+#define T3D_RING_BVH 192   /* in the LBVH kernels, which trade LDS for resident waves (the ring never overflows: see k_level) */
 
 // ------------------------------------------------------------------------------------------------
 // device-side scene
@@ -570,7 +571,7 @@ struct RayIn {
 
 // Everything that follows the closest hit of ONE ray per lane (wave-collective: ballots and atomics):
 // classification, emitter / miss leaves, bounce and transmit rays, node record, queue appends, ring entry.
-template <bool LEVEL0>
+template <bool LEVEL0, int RING>
 __device__ __forceinline__ void process_ray(const DevScene& sc, const DevSphere* __restrict__ spheres, const RenderParams& rp,
                                             const WaveCtx& wc, const RayIn& in, const Hit& h, RayRec* __restrict__ rays_out,
                                             const NodePool& pool, Counters* cnt, const TraceOut& out, float4* ring_a,
@@ -744,7 +745,7 @@ __device__ __forceinline__ void process_ray(const DevScene& sc, const DevSphere*
     }
     // shaded nodes enter the wave's ring in lane order
     if (shaded && wc.L > 0) {
-        const int slot = (ring_nodes + nrank) % T3D_RING;
+        const int slot = (ring_nodes + nrank) % RING;
         ring_a[slot] = make_float4(P.x, P.y, P.z, rough);
         ring_b[slot] = make_float4(N.x, N.y, N.z, __int_as_float(stored ? node : 0));
     }
@@ -803,11 +804,12 @@ __device__ __forceinline__ void load_ray(const DevScene& sc, const RenderParams&
 // per counter per 64 rays.
 // ------------------------------------------------------------------------------------------------
 template <bool LEVEL0, bool BVH>
-__global__ __launch_bounds__(T3D_BLOCK) void k_level(DevScene sc, GEO_PARAMS, RenderParams rp, int level,
+__global__ __launch_bounds__(T3D_BLOCK, BVH ? 5 : 4) void k_level(DevScene sc, GEO_PARAMS, RenderParams rp, int level,
                                                      const RayRec* __restrict__ rays_in, RayRec* __restrict__ rays_out,
                                                      NodePool pool, Counters* cnt, TraceOut out) {
-    __shared__ float4 ring_a_all[T3D_WAVES][T3D_RING];  // P.xyz, roughness
-    __shared__ float4 ring_b_all[T3D_WAVES][T3D_RING];  // unit normal, int bits: node index within the level
+    constexpr int RING = BVH ? T3D_RING_BVH : T3D_RING;
+    __shared__ float4 ring_a_all[T3D_WAVES][RING];  // P.xyz, roughness
+    __shared__ float4 ring_b_all[T3D_WAVES][RING];  // unit normal, int bits: node index within the level
     WaveCtx wc;
     wc.lane = threadIdx.x & 63; wc.wid = threadIdx.x >> 6;
     wc.lt_mask = (1ull << wc.lane) - 1ull;
@@ -840,7 +842,10 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_level(DevScene sc, GEO_PARAMS, Re
     for (;;) {
         const int pending = ring_nodes * L - items_done;
         const bool more = (long long)chunk * cs < n_in;
-        if (pending >= 128 || (!more && pending > 0)) {
+        // nodes whose pairs are all done leave the ring; the next trace round adds up to 128, which must fit
+        // (only the smaller ring of the LBVH kernels can fill up: 256 entries always hold 127 pending + 128 new nodes)
+        const bool ring_full = RING < 256 && L > 0 && (ring_nodes - items_done / L) + 128 > RING;
+        if (pending >= 128 || ((!more || ring_full) && pending > 0)) {
             // ---------------- shadow round: pairs items_done + lane and items_done + 64 + lane ----------------
             const int item0 = items_done + wc.lane, item1 = item0 + 64;
             const bool run0 = item0 < ring_nodes * L, run1 = item1 < ring_nodes * L;
@@ -851,9 +856,9 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_level(DevScene sc, GEO_PARAMS, Re
             const int q0 = (int)(((float)x0 + 0.5f) * inv_L), q1 = (int)(((float)x1 + 0.5f) * inv_L);
             const int nd0 = nd_base + q0, nd1 = nd_base + q1;
             const int l0 = x0 - q0 * L, l1 = x1 - q1 * L;
-            const float4 rb0 = ring_b[nd0 % T3D_RING], rb1 = ring_b[nd1 % T3D_RING];
-            const ShadowRay s0 = shadow_ray(sc, ring_a[nd0 % T3D_RING], rb0, l0);
-            const ShadowRay s1 = shadow_ray(sc, ring_a[nd1 % T3D_RING], rb1, l1);
+            const float4 rb0 = ring_b[nd0 % RING], rb1 = ring_b[nd1 % RING];
+            const ShadowRay s0 = shadow_ray(sc, ring_a[nd0 % RING], rb0, l0);
+            const ShadowRay s1 = shadow_ray(sc, ring_a[nd1 % RING], rb1, l1);
             Hit h0, h1;
             if constexpr (BVH) {
                 bvh_closest(sc, spheres, s0.start, s0.Ld, run0, true, false, h0, bc, &cnt->bvh_stack_overflow);
@@ -878,8 +883,20 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_level(DevScene sc, GEO_PARAMS, Re
             } else {
                 closest_hit2<LEVEL0>(GEO_ARGS, sc.geo, in0.o, in0.d, in1.o, in1.d, lights, in0.ior == 1.0f, in1.ior == 1.0f, h0, h1);
             }
-            process_ray<LEVEL0>(sc, spheres, rp, wc, in0, h0, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes);
-            process_ray<LEVEL0>(sc, spheres, rp, wc, in1, h1, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes);
+            if constexpr (BVH) {
+                // The traversal is bound by memory latency, so registers are worth more as extra waves: the rays are
+                // read again for the classification instead of being kept live across the traversal (the empty asm
+                // makes the index opaque, otherwise the compiler merges the two reads).
+                int idx0 = chunk * cs + wc.lane, idx1 = idx0 + 64;
+                asm volatile("" : "+v"(idx0), "+v"(idx1));
+                load_ray<LEVEL0>(sc, rp, rays_in, idx0, wc.lane < cs ? n_in : 0, queue_base, in0);
+                process_ray<LEVEL0, RING>(sc, spheres, rp, wc, in0, h0, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes);
+                load_ray<LEVEL0>(sc, rp, rays_in, idx1, cs == 128 ? n_in : 0, queue_base, in1);
+                process_ray<LEVEL0, RING>(sc, spheres, rp, wc, in1, h1, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes);
+            } else {
+                process_ray<LEVEL0, RING>(sc, spheres, rp, wc, in0, h0, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes);
+                process_ray<LEVEL0, RING>(sc, spheres, rp, wc, in1, h1, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes);
+            }
             chunk += chunk_step;
             // the ring is private to this wave; LDS operations of one wave complete in order, the fences
             // only stop the compiler from moving the next round's reads above these writes
