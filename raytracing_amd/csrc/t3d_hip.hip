@@ -442,14 +442,15 @@ __device__ __forceinline__ void bvh_closest(const DevScene& sc, const DevSphere*
             if (p < n_tris) {
                 // getFaceCollision (T3DR.py:624-651) for one triangle
                 bc.tris++;
+                // all three rows are requested at once: one memory latency per leaf instead of two on the hit path
                 const float4 rn = sc.tri_n[p];
+                const float4 ra = tri_ab[2 * (size_t)p], rb = tri_ab[2 * (size_t)p + 1];
                 const float dn = fmaf(rn.z, d.z, fmaf(rn.y, d.y, rn.x * d.x));
                 if (fabsf(dn) >= 1e-6f && (!back_cull || dn < 0.0f)) {
                     const float q = fmaf(rn.z, o.z, fmaf(rn.y, o.y, fmaf(rn.x, o.x, rn.w)));
                     const float t = -q * __builtin_amdgcn_rcpf(dn);
                     if (t >= 0.0f && t <= best) {
                         const V3 P = madd(o, d, t);
-                        const float4 ra = tri_ab[2 * (size_t)p], rb = tri_ab[2 * (size_t)p + 1];
                         const float u = fmaf(ra.z, P.z, fmaf(ra.y, P.y, fmaf(ra.x, P.x, ra.w)));
                         const float v = fmaf(rb.z, P.z, fmaf(rb.y, P.y, fmaf(rb.x, P.x, rb.w)));
                         const float w = (1.0f - u) - v;
