@@ -99,7 +99,8 @@ struct DevGeo {
 };
 struct DevBvh {
     const float4* nodes;   // [n_prims - 1] x 4 rows, see t3d_lbvh.h; null when the scene is traced by brute force
-    const float4* tri_ab;  // [2T] per triangle (a.xyz, aw), (b.xyz, bw): u = a.P + aw, v = b.P + bw
+    const float4* tri_ab;  // [4T] per triangle one 64-byte record: (n.xyz, -n.v0), (a.xyz, aw), (b.xyz, bw) with
+                           // u = a.P + aw, v = b.P + bw, and (-, -, -, index in the scene's object / face order as int bits)
     int n_prims;
 };
 struct DevScene {
@@ -443,8 +444,8 @@ __device__ __forceinline__ void bvh_closest(const DevScene& sc, const DevSphere*
                 // getFaceCollision (T3DR.py:624-651) for one triangle
                 bc.tris++;
                 // all three rows are requested at once: one memory latency per leaf instead of two on the hit path
-                const float4 rn = sc.tri_n[p];
-                const float4 ra = tri_ab[2 * (size_t)p], rb = tri_ab[2 * (size_t)p + 1];
+                const float4 rn = tri_ab[4 * (size_t)p], ra = tri_ab[4 * (size_t)p + 1], rb = tri_ab[4 * (size_t)p + 2];
+                const float4 rm = tri_ab[4 * (size_t)p + 3];
                 const float dn = fmaf(rn.z, d.z, fmaf(rn.y, d.y, rn.x * d.x));
                 if (fabsf(dn) >= 1e-6f && (!back_cull || dn < 0.0f)) {
                     const float q = fmaf(rn.z, o.z, fmaf(rn.y, o.y, fmaf(rn.x, o.x, rn.w)));
@@ -455,7 +456,7 @@ __device__ __forceinline__ void bvh_closest(const DevScene& sc, const DevSphere*
                         const float v = fmaf(rb.z, P.z, fmaf(rb.y, P.y, fmaf(rb.x, P.x, rb.w)));
                         const float w = (1.0f - u) - v;
                         if (fminf(fminf(u, v), w) > 0.0f) {
-                            const int rk = sc.tri_meta[p].w;  // index in the scene's object / face order
+                            const int rk = __float_as_int(rm.w);  // index in the scene's object / face order
                             if (t < best || rk < rank) { best = t; prim = p; rank = rk; back = 0; }
                         }
                     }
@@ -1326,7 +1327,7 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
     const bool want_bvh = n_prims >= 2 && (c->accel == T3D_ACCEL_LBVH || (c->accel == T3D_ACCEL_AUTO && n_prims > T3D_BRUTE_FORCE_MAX_PRIMS));
     if (want_bvh) {
         // 3-D barycentric rows  a = (e2 x n) / |n|^2, b = (n x e1) / |n|^2 :  P - v0 = u e1 + v e2  (float64, rounded once)
-        std::vector<float4> tri_ab((size_t)2 * (s->n_tris + 1), make_float4(0.f, 0.f, 0.f, 0.f));
+        std::vector<float4> tri_ab((size_t)4 * (s->n_tris + 1), make_float4(0.f, 0.f, 0.f, 0.f));
         std::vector<float> verts((size_t)9 * (s->n_tris + 1), 0.f);
         for (int k = 0; k < s->n_tris; ++k) {
             const double* v = s->tri_verts + 9 * (size_t)order[k];
@@ -1334,11 +1335,13 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
             const double e1[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]}, e2[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]};
             const double nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
             const double nn = nx * nx + ny * ny + nz * nz;
+            tri_ab[4 * (size_t)k + 0] = tri_n[k];
+            tri_ab[4 * (size_t)k + 3] = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, order[k]));
             if (!(nn > 0)) continue;  // degenerate: rows stay zero, min3(u, v, w) = 0 is never inside
             const double a[3] = {(e2[1] * nz - e2[2] * ny) / nn, (e2[2] * nx - e2[0] * nz) / nn, (e2[0] * ny - e2[1] * nx) / nn};
             const double b[3] = {(ny * e1[2] - nz * e1[1]) / nn, (nz * e1[0] - nx * e1[2]) / nn, (nx * e1[1] - ny * e1[0]) / nn};
-            tri_ab[2 * (size_t)k + 0] = make_float4((float)a[0], (float)a[1], (float)a[2], -(float)(a[0] * v[0] + a[1] * v[1] + a[2] * v[2]) + 0.0f);
-            tri_ab[2 * (size_t)k + 1] = make_float4((float)b[0], (float)b[1], (float)b[2], -(float)(b[0] * v[0] + b[1] * v[1] + b[2] * v[2]) + 0.0f);
+            tri_ab[4 * (size_t)k + 1] = make_float4((float)a[0], (float)a[1], (float)a[2], -(float)(a[0] * v[0] + a[1] * v[1] + a[2] * v[2]) + 0.0f);
+            tri_ab[4 * (size_t)k + 2] = make_float4((float)b[0], (float)b[1], (float)b[2], -(float)(b[0] * v[0] + b[1] * v[1] + b[2] * v[2]) + 0.0f);
         }
         void* d_verts = nullptr;
         if ((rc = upload(c, &c->d_tri_ab, tri_ab)) || (rc = upload(c, &d_verts, verts))) { hipFree(d_verts); return rc; }
