@@ -185,17 +185,17 @@ def main():
             line["roofline"]["traffic"] = tr[0]["hbm_bytes_per_launch"]
             line["roofline"]["traffic_source"] = "profiles/" + tr[1]
         if last["aabb_tests"] > 0:
-            # LBVH traversal: HBM roofline.  Algorithmic bytes: 64 B per node visited (the boxes and links of its
-            # two children), 64 B per triangle test (one leaf record: plane row, two barycentric rows, order index),
-            # 32 B per sphere test.
-            nbytes = 64.0 * (last["aabb_tests"] / 2) + 64.0 * last["tri_tests"] + 32.0 * last["sphere_tests"]
+            # LBVH traversal: HBM roofline.  Algorithmic bytes: 128 B per node record visited (four boxes and links),
+            # 64 B per triangle test (one leaf record: plane row, two barycentric rows, order index), 32 B per
+            # sphere test.
+            nbytes = 128.0 * (last["aabb_tests"] / 4) + 64.0 * last["tri_tests"] + 32.0 * last["sphere_tests"]
             gbs = nbytes / level_s / 1e9 if level_s > 0 else 0.0
             line["roofline"] = {"bound": "hbm", "kernel": "k_level (LBVH traversal)", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
                                 "launches_per_frame": last["n_k_level"],
                                 "avg_launch_ms": round(last["ms_k_level"] / max(1, last["n_k_level"]), 5),
                                 "bytes_per_launch": nbytes / max(1, last["n_k_level"]),
-                                "nodes_visited_per_query": round(last["aabb_tests"] / 2 / max(1, last["queries"]), 2),
+                                "nodes_visited_per_query": round(last["aabb_tests"] / 4 / max(1, last["queries"]), 2),
                                 "tri_tests_per_query": round(last["tri_tests"] / max(1, last["queries"]), 2),
                                 "frame_device_ms": round(last["ms_device"], 4), "resolve_ms": round(last["ms_resolve"], 4)}
             line["metric"] = f"Mrays/s (primary+secondary closest-hit queries), {args.workload}"

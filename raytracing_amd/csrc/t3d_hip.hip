@@ -98,7 +98,7 @@ struct DevGeo {
     float box_lo[3], box_hi[3];  // bounds of every triangle and sphere, padded outward
 };
 struct DevBvh {
-    const float4* nodes;   // [n_prims - 1] x 4 rows, see t3d_lbvh.h; null when the scene is traced by brute force
+    const float4* nodes;   // [n_prims - 1] x 8 rows, see t3d_lbvh.h; null when the scene is traced by brute force
     const float4* tri_ab;  // [4T] per triangle one 64-byte record: (n.xyz, -n.v0), (a.xyz, aw), (b.xyz, bw) with
                            // u = a.P + aw, v = b.P + bw, and (-, -, -, index in the scene's object / face order as int bits)
     int n_prims;
@@ -391,7 +391,7 @@ __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0
 // Same acceptance rules as the brute-force loop; equal distances go to the primitive that comes first in
 // the scene's object / face order, whatever order the traversal meets them in.
 // ------------------------------------------------------------------------------------------------
-#define T3D_BVH_STACK 64
+#define T3D_BVH_STACK 96
 struct BvhCount {
     uint32_t nodes, tris, spheres;
 };
@@ -415,29 +415,40 @@ __device__ __forceinline__ void bvh_closest(const DevScene& sc, const DevSphere*
     int node = 0;          // so the private-memory read is off the critical path
     for (;;) {
         if (node >= 0) {
-            const float4 r0 = nodes[4 * (size_t)node + 0], r1 = nodes[4 * (size_t)node + 1];
-            const float4 r2 = nodes[4 * (size_t)node + 2], r3 = nodes[4 * (size_t)node + 3];
+            const float4* __restrict__ rec = nodes + 8 * (size_t)node;
+            const float4 lx = rec[0], ly = rec[1], lz = rec[2], hx = rec[3], hy = rec[4], hz = rec[5], lk = rec[6];
             bc.nodes++;
-            // slabs: t = (plane - o) / d = plane * inv + oi
-            const float ax0 = fmaf(r0.x, inv.x, oi.x), bx0 = fmaf(r0.w, inv.x, oi.x);
-            const float ay0 = fmaf(r0.y, inv.y, oi.y), by0 = fmaf(r1.x, inv.y, oi.y);
-            const float az0 = fmaf(r0.z, inv.z, oi.z), bz0 = fmaf(r1.y, inv.z, oi.z);
-            const float ax1 = fmaf(r1.z, inv.x, oi.x), bx1 = fmaf(r2.y, inv.x, oi.x);
-            const float ay1 = fmaf(r1.w, inv.y, oi.y), by1 = fmaf(r2.z, inv.y, oi.y);
-            const float az1 = fmaf(r2.x, inv.z, oi.z), bz1 = fmaf(r2.w, inv.z, oi.z);
-            const float n0 = fmaxf(fmaxf(fminf(ax0, bx0), fminf(ay0, by0)), fmaxf(fminf(az0, bz0), 0.0f));
-            const float f0 = fminf(fminf(fmaxf(ax0, bx0), fmaxf(ay0, by0)), fminf(fmaxf(az0, bz0), best)) * 1.0000004f;
-            const float n1 = fmaxf(fmaxf(fminf(ax1, bx1), fminf(ay1, by1)), fmaxf(fminf(az1, bz1), 0.0f));
-            const float f1 = fminf(fminf(fmaxf(ax1, bx1), fmaxf(ay1, by1)), fminf(fmaxf(az1, bz1), best)) * 1.0000004f;
-            const bool h0 = n0 <= f0, h1 = n1 <= f1;
-            const int c0 = __float_as_int(r3.x), c1 = __float_as_int(r3.y);
-            if (h0 & h1) {
-                const bool first0 = n0 <= n1;
-                if (sp < T3D_BVH_STACK) { top = first0 ? c1 : c0; stack[sp++] = top; } else *stack_overflow = 1;
-                node = first0 ? c0 : c1;
-                continue;
+            // slabs of the four slots: t = (plane - o) / d = plane * inv + oi; a slot is entered while its interval
+            // reaches the best distance so far (<=: equal distances must all be seen); empty slots never are
+            float tn[4];
+            int ln[4] = {__float_as_int(lk.x), __float_as_int(lk.y), __float_as_int(lk.z), __float_as_int(lk.w)};
+            const float lxa[4] = {lx.x, lx.y, lx.z, lx.w}, lya[4] = {ly.x, ly.y, ly.z, ly.w}, lza[4] = {lz.x, lz.y, lz.z, lz.w};
+            const float hxa[4] = {hx.x, hx.y, hx.z, hx.w}, hya[4] = {hy.x, hy.y, hy.z, hy.w}, hza[4] = {hz.x, hz.y, hz.z, hz.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float ax = fmaf(lxa[k], inv.x, oi.x), bx = fmaf(hxa[k], inv.x, oi.x);
+                const float ay = fmaf(lya[k], inv.y, oi.y), by = fmaf(hya[k], inv.y, oi.y);
+                const float az = fmaf(lza[k], inv.z, oi.z), bz = fmaf(hza[k], inv.z, oi.z);
+                const float near = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+                const float far = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best)) * 1.0000004f;
+                tn[k] = near <= far ? near : __builtin_inff();   // +inf: not entered
             }
-            if (h0 | h1) { node = h0 ? c0 : c1; continue; }
+            // order the slots by entry distance (5 compare-exchanges), nearest first
+            auto cswap = [&](int a, int b) {
+                const bool sw = tn[b] < tn[a];
+                const float ta = sw ? tn[b] : tn[a], tb = sw ? tn[a] : tn[b];
+                const int la = sw ? ln[b] : ln[a], lb = sw ? ln[a] : ln[b];
+                tn[a] = ta; tn[b] = tb; ln[a] = la; ln[b] = lb;
+            };
+            cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2);
+            // push the entered slots 3, 2, 1 (farthest first), descend into slot 0
+#pragma unroll
+            for (int k = 3; k >= 1; --k) {
+                if (tn[k] < __builtin_inff()) {
+                    if (sp < T3D_BVH_STACK) { top = ln[k]; stack[sp++] = top; } else *stack_overflow = 1;
+                }
+            }
+            if (tn[0] < __builtin_inff()) { node = ln[0]; continue; }
         } else {
             const int p = ~node;
             if (p < n_tris) {
@@ -1458,7 +1469,7 @@ static void fill_stats(t3d_ctx* c, t3d_stats* stats) {
     if (c->use_bvh) {
         uint64_t nv = 0, tt = 0, stt = 0;
         for (int sh = 0; sh < T3D_SHARDS; ++sh) { nv += c->h_cnt->bvh_stat[sh][0]; tt += c->h_cnt->bvh_stat[sh][1]; stt += c->h_cnt->bvh_stat[sh][2]; }
-        stats->aabb_tests += 2 * nv;  // every node visited holds the boxes of its two children
+        stats->aabb_tests += 4 * nv;  // every record visited holds four boxes
         stats->tri_tests += tt;
         stats->sphere_tests += stt;
     } else {

@@ -13,11 +13,6 @@
 
 #define LBVH_BLOCK 256
 
-// 64-byte traversal node: the boxes of BOTH children and their links, so one fetch decides two subtrees.
-//   r0 = (lo0.x, lo0.y, lo0.z, hi0.x)  r1 = (hi0.y, hi0.z, lo1.x, lo1.y)
-//   r2 = (lo1.z, hi1.x, hi1.y, hi1.z)  r3 = (child0, child1, 0, 0) as int bits
-// child >= 0: internal node index; child < 0: leaf holding primitive ~child
-// (primitive p < n_tris: triangle p in device order; otherwise sphere p - n_tris).
 struct LbvhWork {
     float4* prim_lo = nullptr;   // [N] box of primitive p (w unused)
     float4* prim_hi = nullptr;
@@ -219,28 +214,54 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_refit(const int* __restrict
     }
 }
 
-// Traversal nodes: both child boxes and links in one 64-byte record.
+// Traversal nodes, 4 wide: the record of binary node i holds the boxes and links of its GRANDchildren (a child
+// that is a leaf takes one slot itself), so one fetch decides four subtrees and a ray makes half as many dependent
+// fetches on its way down.  128 bytes, structure of arrays over the four slots:
+//   rows 0..2 = lo.x, lo.y, lo.z of slots 0..3;  rows 3..5 = hi.x, hi.y, hi.z;  row 6 = links as int bits;  row 7 unused
+// link >= 0: binary node index (whose own record is the next fetch); link < 0: leaf holding primitive ~link
+// (primitive p < n_tris: triangle p in device order; otherwise sphere p - n_tris).  Unused slots hold a box that is
+// a single point at 1e38 on every axis: its slab interval is empty for every ray (an inverted box would not do, the
+// slab test is symmetric in lo and hi).
 __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_pack(const int* __restrict__ vals, int n, const float4* __restrict__ prim_lo,
                                                           const float4* __restrict__ prim_hi, const int2* __restrict__ kids,
                                                           const float4* __restrict__ box_lo, const float4* __restrict__ box_hi,
                                                           float4* __restrict__ nodes) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
+    float lo[3][4], hi[3][4];
+    int link[4];
+    for (int k = 0; k < 4; ++k) {
+        for (int a = 0; a < 3; ++a) { lo[a][k] = 1e38f; hi[a][k] = 1e38f; }   // a point no ray reaches before its best hit
+        link[k] = 0;
+    }
+    int slot = 0;
+    auto put = [&](int id) {   // id: internal node (< n - 1) or leaf (n - 1 + sorted position)
+        float4 l, h;
+        int c;
+        if (id >= n - 1) { const int p = vals[id - (n - 1)]; l = prim_lo[p]; h = prim_hi[p]; c = ~p; }
+        else { l = box_lo[id]; h = box_hi[id]; c = id; }
+        lo[0][slot] = l.x; lo[1][slot] = l.y; lo[2][slot] = l.z;
+        hi[0][slot] = h.x; hi[1][slot] = h.y; hi[2][slot] = h.z;
+        link[slot] = c;
+        ++slot;
+    };
     const int2 k = kids[i];
-    float4 l0, h0, l1, h1;
-    int c0, c1;
-    if (k.x >= n - 1) { const int p = vals[k.x - (n - 1)]; l0 = prim_lo[p]; h0 = prim_hi[p]; c0 = ~p; }
-    else { l0 = box_lo[k.x]; h0 = box_hi[k.x]; c0 = k.x; }
-    if (k.y >= n - 1) { const int p = vals[k.y - (n - 1)]; l1 = prim_lo[p]; h1 = prim_hi[p]; c1 = ~p; }
-    else { l1 = box_lo[k.y]; h1 = box_hi[k.y]; c1 = k.y; }
-    nodes[4 * (size_t)i + 0] = make_float4(l0.x, l0.y, l0.z, h0.x);
-    nodes[4 * (size_t)i + 1] = make_float4(h0.y, h0.z, l1.x, l1.y);
-    nodes[4 * (size_t)i + 2] = make_float4(l1.z, h1.x, h1.y, h1.z);
-    nodes[4 * (size_t)i + 3] = make_float4(__int_as_float(c0), __int_as_float(c1), 0.f, 0.f);
+    const int child[2] = {k.x, k.y};
+    for (int c = 0; c < 2; ++c) {
+        if (child[c] >= n - 1) put(child[c]);
+        else { const int2 g = kids[child[c]]; put(g.x); put(g.y); }
+    }
+    float4* out = nodes + 8 * (size_t)i;
+    for (int a = 0; a < 3; ++a) {
+        out[a] = make_float4(lo[a][0], lo[a][1], lo[a][2], lo[a][3]);
+        out[3 + a] = make_float4(hi[a][0], hi[a][1], hi[a][2], hi[a][3]);
+    }
+    out[6] = make_float4(__int_as_float(link[0]), __int_as_float(link[1]), __int_as_float(link[2]), __int_as_float(link[3]));
+    out[7] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // Build the hierarchy over n_tris triangles (vertices in device order, 9 floats each) and n_spheres
-// spheres; *out_nodes receives n - 1 traversal nodes (hipMalloc, owned by the caller).  Needs n >= 2.
+// spheres; *out_nodes receives n - 1 traversal nodes of 128 bytes (hipMalloc, owned by the caller).  Needs n >= 2.
 static hipError_t lbvh_build(hipStream_t st, const float* d_verts, int n_tris, const DevSphere* d_spheres, int n_spheres,
                              float4** out_nodes) {
     const int n = n_tris + n_spheres;
@@ -257,7 +278,7 @@ static hipError_t lbvh_build(hipStream_t st, const float* d_verts, int n_tris, c
     LB(hipMalloc(&w.parent, sizeof(int) * (2 * (size_t)n - 1))); LB(hipMalloc(&w.kids, sizeof(int2) * (n - 1)));
     LB(hipMalloc(&w.box_lo, sizeof(float4) * (n - 1))); LB(hipMalloc(&w.box_hi, sizeof(float4) * (n - 1)));
     LB(hipMalloc(&w.flags, sizeof(int) * (n - 1))); LB(hipMalloc(&w.bounds, sizeof(int) * 6));
-    LB(hipMalloc(&nodes, sizeof(float4) * 4 * (size_t)(n - 1)));
+    LB(hipMalloc(&nodes, sizeof(float4) * 8 * (size_t)(n - 1)));
     const int init_bounds[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
     LB(hipMemcpyAsync(w.bounds, init_bounds, sizeof init_bounds, hipMemcpyHostToDevice, st));
     LB(hipStreamSynchronize(st));  // init_bounds is a stack array
