@@ -391,7 +391,12 @@ __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0
 // Same acceptance rules as the brute-force loop; equal distances go to the primitive that comes first in
 // the scene's object / face order, whatever order the traversal meets them in.
 // ------------------------------------------------------------------------------------------------
+#ifndef T3D_BVH_STACK
 #define T3D_BVH_STACK 96
+#endif
+#ifndef T3D_BVH_WAVES
+#define T3D_BVH_WAVES 5   // waves per SIMD the traversal kernels are compiled for
+#endif
 struct BvhCount {
     uint32_t nodes, tris, spheres;
 };
@@ -817,7 +822,7 @@ __device__ __forceinline__ void load_ray(const DevScene& sc, const RenderParams&
 // per counter per 64 rays.
 // ------------------------------------------------------------------------------------------------
 template <bool LEVEL0, bool BVH>
-__global__ __launch_bounds__(T3D_BLOCK, BVH ? 5 : 4) void k_level(DevScene sc, GEO_PARAMS, RenderParams rp, int level,
+__global__ __launch_bounds__(T3D_BLOCK, BVH ? T3D_BVH_WAVES : 4) void k_level(DevScene sc, GEO_PARAMS, RenderParams rp, int level,
                                                      const RayRec* __restrict__ rays_in, RayRec* __restrict__ rays_out,
                                                      NodePool pool, Counters* cnt, TraceOut out) {
     constexpr int RING = BVH ? T3D_RING_BVH : T3D_RING;

@@ -17,7 +17,7 @@ The arrays are laid out exactly as ``t3d_scene_desc`` (include/t3d.h) wants them
 from __future__ import annotations
 
 import ctypes as C
-from dataclasses import dataclass, field
+from dataclasses import dataclass, field, fields
 
 import numpy as np
 
@@ -135,6 +135,20 @@ class FlatScene:
     def n_spheres(self):
         """analytic primitives a closest-hit query may test: spheres + lights"""
         return int(np.count_nonzero((self.obj_type == OBJ_SPHERE) | (self.obj_type == OBJ_LIGHT)))
+
+    def digest(self) -> bytes:
+        """Fingerprint of everything the device copy is built from: two flattenings with equal digests upload
+        the same scene, so the second upload (plane grouping, hierarchy build) can be skipped."""
+        import hashlib
+        h = hashlib.blake2b(digest_size=16)
+        for f in fields(self):
+            v = getattr(self, f.name)
+            if isinstance(v, np.ndarray):
+                h.update(f.name.encode() + str(v.shape).encode() + str(v.dtype).encode())
+                h.update(np.ascontiguousarray(v).view(np.uint8).tobytes() if v.size else b"")
+            elif f.name != "obj_ids":
+                h.update(f.name.encode() + np.asarray(v, np.float64).tobytes())
+        return h.digest()
 
     def as_desc(self) -> SceneDesc:
         d = SceneDesc()

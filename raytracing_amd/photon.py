@@ -151,6 +151,8 @@ class Photon:
         self._ctx = None
         self._flat = None
         self._baked = None
+        self._uploaded_digest = None
+        self.uploads = 0           # scene uploads so far (a re-flattening with an unchanged digest is not one)
         self.scene = scene
         self.options = self.mergeDefaultOptions({} if options is None else options)
         self.rays = 0
@@ -207,8 +209,15 @@ class Photon:
         if self._scene.camera is None:
             raise NoBoundCameraError()
         if force or self._flat is None or not self.options["transformBefore"]:
-            self._flat = flatten_scene(self._scene)
-            self._context().upload(self._flat)
+            flat = flatten_scene(self._scene)
+            digest = flat.digest()
+            # an unchanged scene keeps its device copy (plane groups, hierarchy): a picking loop over a scene
+            # that is not being edited pays for the flattening only
+            if force or digest != self._uploaded_digest:
+                self._context().upload(flat)
+                self._uploaded_digest = digest
+                self.uploads += 1
+            self._flat = flat
         return self._context()
 
     def _native_options(self):

@@ -281,6 +281,31 @@ def test_photon_trace_compute_color_direct_light(gpu_ctx):
     assert tree is not None and tree.collisionInfo["object"].id == cube.id and tree.collisionInfo["direction"] == 1
 
 
+def test_picking_on_a_live_scene(gpu_ctx):
+    """transformBefore False (explorer.py:324-355): every query sees the scene as it is now; an unchanged scene
+    keeps its device copy."""
+    import T3DE
+    import T3DR
+    scene = T3DE.Scene.fromJSON(str(__import__("os").path.join(__import__("conftest").SCENES, "cornellScene.json")))
+    photon = T3DR.Photon(scene, {"width": 64, "height": 48, "transformBefore": False})
+    ray = photon.getRay(photon.pixelToVector(32, 30))
+    first = photon.getFirstCollision(ray, True, False)
+    again = photon.getFirstCollision(ray, True, False)
+    assert first["object"] is not None and again["object"] is first["object"] and again["t"] == first["t"]
+    assert photon.uploads == 1
+    baked = T3DR.Photon(scene, {"width": 64, "height": 48}).getFirstCollision(ray, True, False)
+    assert baked["object"].id == first["object"].id and baked["t"] == first["t"]
+    obj = first["object"]                       # the caller's own object: the live path does not copy the scene
+    assert any(o is obj for o in scene.objects)
+    obj.position = T3DE.Vec3(obj.position.x + 100.0, obj.position.y, obj.position.z)
+    moved = photon.getFirstCollision(ray, True, False)
+    assert photon.uploads == 2
+    assert moved["object"] is not obj
+    obj.position = T3DE.Vec3(obj.position.x - 100.0, obj.position.y, obj.position.z)
+    back = photon.getFirstCollision(ray, True, False)
+    assert photon.uploads == 3 and back["object"] is obj and back["t"] == first["t"]
+
+
 def test_bench_line_contract():
     """bench.py prints one JSON line with the fields the driver reads, a roofline and a CPU baseline."""
     import json

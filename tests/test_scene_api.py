@@ -190,3 +190,22 @@ def test_rendered_json_round_trip(tmp_path):
     # the compressed form survives the same path
     packed = T3DR.Post.compressRenderedDict(r.toDict(), tolerance=0)
     assert np.array_equal(T3DR.Rendered.fromDict(T3DR.Post.decompressRenderedDict(packed)).imageAs("np"), r.imageAs("np"))
+
+
+def test_flat_scene_digest_tracks_every_input():
+    """Equal flattenings have equal digests; moving an object, a shader value or the camera changes it."""
+    import T3DE
+    from raytracing_amd.flatten import flatten_scene
+    path = os.path.join(SCENES, "cornellScene.json")
+    a, b = T3DE.Scene.fromJSON(path), T3DE.Scene.fromJSON(path)
+    base = flatten_scene(a).digest()
+    assert flatten_scene(b).digest() == base and len(base) == 16
+    mesh = next(o for o in b.objects if o.type == "mesh")
+    mesh.position = T3DE.Vec3(mesh.position.x + 1e-6, mesh.position.y, mesh.position.z)
+    assert flatten_scene(b).digest() != base
+    c = T3DE.Scene.fromJSON(path)
+    c.camera.length = c.camera.length * 2
+    assert flatten_scene(c).digest() != base
+    d = T3DE.Scene.fromJSON(path)
+    next(o for o in d.objects if o.type == "mesh").shaders[0].roughness += 0.25
+    assert flatten_scene(d).digest() != base
