@@ -198,6 +198,9 @@ def main():
                                 "nodes_visited_per_query": round(last["aabb_tests"] / 4 / max(1, last["queries"]), 2),
                                 "tri_tests_per_query": round(last["tri_tests"] / max(1, last["queries"]), 2),
                                 "frame_device_ms": round(last["ms_device"], 4), "resolve_ms": round(last["ms_resolve"], 4)}
+            if tr:
+                line["roofline"]["traffic"] = tr[0]["hbm_bytes_per_launch"]
+                line["roofline"]["traffic_source"] = "profiles/" + tr[1]
             line["metric"] = f"Mrays/s (primary+secondary closest-hit queries), {args.workload}"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(flat, options, seed, row_step=args.cpu_row_step or (1 if args.workload == "cornell_1080p_b4" else 0))

@@ -51,7 +51,6 @@
 #define T3D_MAX_BOUNCES 14 /* heap index of the deepest node must fit 16 bits of the RNG key */
 #define T3D_SHARDS 64      /* queue shards per level; every launch holds a multiple of 64 waves */
 #define T3D_RING 256       /* nodes per wave in the brute-force kernels: < 128 pairs pending before a trace round, which adds <= 128 nodes */
-#define T3D_RING_BVH 192   /* in the LBVH kernels, which trade LDS for resident waves (the ring never overflows: see k_level) */
 
 // ------------------------------------------------------------------------------------------------
 // device-side scene
@@ -401,109 +400,135 @@ struct BvhCount {
     uint32_t nodes, tris, spheres;
 };
 
+// Traversal state of one ray (one lane).  bvh_begin sets it up, bvh_step advances it by one node record or one
+// leaf and says whether the ray is finished, so that a caller may hand the lane its next ray at once instead of
+// waiting for the slowest ray of the wave.
+struct BvhLane {
+    V3 o, d, inv, oi;
+    float best;
+    int prim, rank, back;
+    int sp, top;   // top mirrors stack[sp - 1]: a pop uses it at once and only then fetches the entry below,
+    int node;      // so the private-memory read is off the critical path
+    bool lights, back_cull;
+};   // the stack is a separate array: inside the structure it would drag every field into private memory
+
+__device__ __forceinline__ void bvh_begin(BvhLane& s, V3 o, V3 d, bool lights, bool back_cull) {
+    s.o = o; s.d = d;
+    // 1/d with zero components replaced by a huge finite value: 0 * inf would be NaN on a box face
+    const float BIGF = 1e30f;
+    s.inv = mk(fminf(fmaxf(__builtin_amdgcn_rcpf(d.x), -BIGF), BIGF), fminf(fmaxf(__builtin_amdgcn_rcpf(d.y), -BIGF), BIGF),
+               fminf(fmaxf(__builtin_amdgcn_rcpf(d.z), -BIGF), BIGF));
+    s.oi = mk(-o.x * s.inv.x, -o.y * s.inv.y, -o.z * s.inv.z);
+    s.best = __builtin_inff();
+    s.prim = -1; s.back = 0; s.rank = 0x7fffffff;
+    s.sp = 0; s.top = 0; s.node = 0;
+    s.lights = lights; s.back_cull = back_cull;
+}
+
+// One step: a node record (four slab tests, entered slots pushed far to near, nearest descended into) or a leaf
+// (one triangle or sphere).  Returns true when nothing is left on the stack.
+__device__ __forceinline__ bool bvh_step(const DevScene& sc, const DevSphere* __restrict__ spheres, BvhLane& s, int (&stack)[T3D_BVH_STACK],
+                                         BvhCount& bc, int* stack_overflow) {
+    const float4* __restrict__ nodes = sc.bvh.nodes;
+    const float4* __restrict__ tri_ab = sc.bvh.tri_ab;
+    const int n_tris = sc.n_tris;
+    const V3 o = s.o, d = s.d, inv = s.inv, oi = s.oi;
+    if (s.node >= 0) {
+        const float4* __restrict__ rec = nodes + 8 * (size_t)s.node;
+        const float4 lx = rec[0], ly = rec[1], lz = rec[2], hx = rec[3], hy = rec[4], hz = rec[5], lk = rec[6];
+        bc.nodes++;
+        // slabs of the four slots: t = (plane - o) / d = plane * inv + oi; a slot is entered while its interval
+        // reaches the best distance so far (<=: equal distances must all be seen); empty slots never are
+        float tn[4];
+        int ln[4] = {__float_as_int(lk.x), __float_as_int(lk.y), __float_as_int(lk.z), __float_as_int(lk.w)};
+        const float lxa[4] = {lx.x, lx.y, lx.z, lx.w}, lya[4] = {ly.x, ly.y, ly.z, ly.w}, lza[4] = {lz.x, lz.y, lz.z, lz.w};
+        const float hxa[4] = {hx.x, hx.y, hx.z, hx.w}, hya[4] = {hy.x, hy.y, hy.z, hy.w}, hza[4] = {hz.x, hz.y, hz.z, hz.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float ax = fmaf(lxa[k], inv.x, oi.x), bx = fmaf(hxa[k], inv.x, oi.x);
+            const float ay = fmaf(lya[k], inv.y, oi.y), by = fmaf(hya[k], inv.y, oi.y);
+            const float az = fmaf(lza[k], inv.z, oi.z), bz = fmaf(hza[k], inv.z, oi.z);
+            const float near = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+            const float far = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), s.best)) * 1.0000004f;
+            tn[k] = near <= far ? near : __builtin_inff();   // +inf: not entered
+        }
+        // order the slots by entry distance (5 compare-exchanges), nearest first
+        auto cswap = [&](int a, int b) {
+            const bool sw = tn[b] < tn[a];
+            const float ta = sw ? tn[b] : tn[a], tb = sw ? tn[a] : tn[b];
+            const int la = sw ? ln[b] : ln[a], lb = sw ? ln[a] : ln[b];
+            tn[a] = ta; tn[b] = tb; ln[a] = la; ln[b] = lb;
+        };
+        cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2);
+        // push the entered slots 3, 2, 1 (farthest first), descend into slot 0
+#pragma unroll
+        for (int k = 3; k >= 1; --k) {
+            if (tn[k] < __builtin_inff()) {
+                if (s.sp < T3D_BVH_STACK) { s.top = ln[k]; stack[s.sp++] = s.top; } else *stack_overflow = 1;
+            }
+        }
+        if (tn[0] < __builtin_inff()) { s.node = ln[0]; return false; }
+    } else {
+        const int p = ~s.node;
+        if (p < n_tris) {
+            // getFaceCollision (T3DR.py:624-651) for one triangle
+            bc.tris++;
+            // all rows are requested at once: one memory latency per leaf instead of two on the hit path
+            const float4 rn = tri_ab[4 * (size_t)p], ra = tri_ab[4 * (size_t)p + 1], rb = tri_ab[4 * (size_t)p + 2];
+            const float4 rm = tri_ab[4 * (size_t)p + 3];
+            const float dn = fmaf(rn.z, d.z, fmaf(rn.y, d.y, rn.x * d.x));
+            if (fabsf(dn) >= 1e-6f && (!s.back_cull || dn < 0.0f)) {
+                const float q = fmaf(rn.z, o.z, fmaf(rn.y, o.y, fmaf(rn.x, o.x, rn.w)));
+                const float t = -q * __builtin_amdgcn_rcpf(dn);
+                if (t >= 0.0f && t <= s.best) {
+                    const V3 P = madd(o, d, t);
+                    const float u = fmaf(ra.z, P.z, fmaf(ra.y, P.y, fmaf(ra.x, P.x, ra.w)));
+                    const float v = fmaf(rb.z, P.z, fmaf(rb.y, P.y, fmaf(rb.x, P.x, rb.w)));
+                    const float w = (1.0f - u) - v;
+                    if (fminf(fminf(u, v), w) > 0.0f) {
+                        const int rk = __float_as_int(rm.w);  // index in the scene's object / face order
+                        if (t < s.best || rk < s.rank) { s.best = t; s.prim = p; s.rank = rk; s.back = 0; }
+                    }
+                }
+            }
+        } else {
+            // getSphereCollision (T3DR.py:572-598)
+            const DevSphere sp = spheres[p - n_tris];
+            if (!sp.is_light || s.lights) {
+                bc.spheres++;
+                const V3 Lv = mk(o.x - sp.cx, o.y - sp.cy, o.z - sp.cz);
+                const float b = dot(Lv, d);
+                const V3 qv = madd(Lv, d, -b);  // L - b d: see closest_hit2
+                const float disc = sp.r2 - dot(qv, qv);
+                if (disc >= 0.0f) {
+                    const float root = __builtin_amdgcn_sqrtf(disc);
+                    const float t1 = -b - root, t2 = -b + root;
+                    const bool front = t1 > 0.0f;
+                    const bool inside = (!front) & (t2 > 0.0f) & (!s.back_cull) & (sp.is_light == 0);
+                    const float t = front ? t1 : t2;
+                    const int rk = 0x40000000 + (p - n_tris);  // spheres after all triangles on equal distance
+                    if ((front | inside) && (t < s.best || (t == s.best && rk < s.rank))) { s.best = t; s.prim = p; s.rank = rk; s.back = front ? 0 : 1; }
+                }
+            }
+        }
+    }
+    if (s.sp == 0) return true;
+    s.node = s.top;
+    --s.sp;
+    s.top = stack[s.sp > 0 ? s.sp - 1 : 0];
+    return false;
+}
+
+// Closest hit of one ray per lane; every lane runs until its own ray is finished.
 __device__ __forceinline__ void bvh_closest(const DevScene& sc, const DevSphere* __restrict__ spheres, V3 o, V3 d, bool active,
                                             bool lights, bool back_cull, Hit& out, BvhCount& bc, int* stack_overflow) {
     out.t = __builtin_inff(); out.prim = -1; out.back = 0;
     if (!active) return;
-    const float4* __restrict__ nodes = sc.bvh.nodes;
-    const float4* __restrict__ tri_ab = sc.bvh.tri_ab;
-    const int n_tris = sc.n_tris;
-    // 1/d with zero components replaced by a huge finite value: 0 * inf would be NaN on a box face
-    const float BIGF = 1e30f;
-    const V3 inv = mk(fminf(fmaxf(__builtin_amdgcn_rcpf(d.x), -BIGF), BIGF), fminf(fmaxf(__builtin_amdgcn_rcpf(d.y), -BIGF), BIGF),
-                      fminf(fmaxf(__builtin_amdgcn_rcpf(d.z), -BIGF), BIGF));
-    const V3 oi = mk(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
-    float best = __builtin_inff();
-    int prim = -1, back = 0, rank = 0x7fffffff;
+    BvhLane s;
     int stack[T3D_BVH_STACK];
-    int sp = 0, top = 0;   // top mirrors stack[sp - 1]: a pop uses it at once and only then fetches the entry below,
-    int node = 0;          // so the private-memory read is off the critical path
-    for (;;) {
-        if (node >= 0) {
-            const float4* __restrict__ rec = nodes + 8 * (size_t)node;
-            const float4 lx = rec[0], ly = rec[1], lz = rec[2], hx = rec[3], hy = rec[4], hz = rec[5], lk = rec[6];
-            bc.nodes++;
-            // slabs of the four slots: t = (plane - o) / d = plane * inv + oi; a slot is entered while its interval
-            // reaches the best distance so far (<=: equal distances must all be seen); empty slots never are
-            float tn[4];
-            int ln[4] = {__float_as_int(lk.x), __float_as_int(lk.y), __float_as_int(lk.z), __float_as_int(lk.w)};
-            const float lxa[4] = {lx.x, lx.y, lx.z, lx.w}, lya[4] = {ly.x, ly.y, ly.z, ly.w}, lza[4] = {lz.x, lz.y, lz.z, lz.w};
-            const float hxa[4] = {hx.x, hx.y, hx.z, hx.w}, hya[4] = {hy.x, hy.y, hy.z, hy.w}, hza[4] = {hz.x, hz.y, hz.z, hz.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float ax = fmaf(lxa[k], inv.x, oi.x), bx = fmaf(hxa[k], inv.x, oi.x);
-                const float ay = fmaf(lya[k], inv.y, oi.y), by = fmaf(hya[k], inv.y, oi.y);
-                const float az = fmaf(lza[k], inv.z, oi.z), bz = fmaf(hza[k], inv.z, oi.z);
-                const float near = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-                const float far = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best)) * 1.0000004f;
-                tn[k] = near <= far ? near : __builtin_inff();   // +inf: not entered
-            }
-            // order the slots by entry distance (5 compare-exchanges), nearest first
-            auto cswap = [&](int a, int b) {
-                const bool sw = tn[b] < tn[a];
-                const float ta = sw ? tn[b] : tn[a], tb = sw ? tn[a] : tn[b];
-                const int la = sw ? ln[b] : ln[a], lb = sw ? ln[a] : ln[b];
-                tn[a] = ta; tn[b] = tb; ln[a] = la; ln[b] = lb;
-            };
-            cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2);
-            // push the entered slots 3, 2, 1 (farthest first), descend into slot 0
-#pragma unroll
-            for (int k = 3; k >= 1; --k) {
-                if (tn[k] < __builtin_inff()) {
-                    if (sp < T3D_BVH_STACK) { top = ln[k]; stack[sp++] = top; } else *stack_overflow = 1;
-                }
-            }
-            if (tn[0] < __builtin_inff()) { node = ln[0]; continue; }
-        } else {
-            const int p = ~node;
-            if (p < n_tris) {
-                // getFaceCollision (T3DR.py:624-651) for one triangle
-                bc.tris++;
-                // all three rows are requested at once: one memory latency per leaf instead of two on the hit path
-                const float4 rn = tri_ab[4 * (size_t)p], ra = tri_ab[4 * (size_t)p + 1], rb = tri_ab[4 * (size_t)p + 2];
-                const float4 rm = tri_ab[4 * (size_t)p + 3];
-                const float dn = fmaf(rn.z, d.z, fmaf(rn.y, d.y, rn.x * d.x));
-                if (fabsf(dn) >= 1e-6f && (!back_cull || dn < 0.0f)) {
-                    const float q = fmaf(rn.z, o.z, fmaf(rn.y, o.y, fmaf(rn.x, o.x, rn.w)));
-                    const float t = -q * __builtin_amdgcn_rcpf(dn);
-                    if (t >= 0.0f && t <= best) {
-                        const V3 P = madd(o, d, t);
-                        const float u = fmaf(ra.z, P.z, fmaf(ra.y, P.y, fmaf(ra.x, P.x, ra.w)));
-                        const float v = fmaf(rb.z, P.z, fmaf(rb.y, P.y, fmaf(rb.x, P.x, rb.w)));
-                        const float w = (1.0f - u) - v;
-                        if (fminf(fminf(u, v), w) > 0.0f) {
-                            const int rk = __float_as_int(rm.w);  // index in the scene's object / face order
-                            if (t < best || rk < rank) { best = t; prim = p; rank = rk; back = 0; }
-                        }
-                    }
-                }
-            } else {
-                // getSphereCollision (T3DR.py:572-598)
-                const DevSphere s = spheres[p - n_tris];
-                if (!s.is_light || lights) {
-                    bc.spheres++;
-                    const V3 Lv = mk(o.x - s.cx, o.y - s.cy, o.z - s.cz);
-                    const float b = dot(Lv, d);
-                    const V3 qv = madd(Lv, d, -b);  // L - b d: see closest_hit2
-                    const float disc = s.r2 - dot(qv, qv);
-                    if (disc >= 0.0f) {
-                        const float root = __builtin_amdgcn_sqrtf(disc);
-                        const float t1 = -b - root, t2 = -b + root;
-                        const bool front = t1 > 0.0f;
-                        const bool inside = (!front) & (t2 > 0.0f) & (!back_cull) & (s.is_light == 0);
-                        const float t = front ? t1 : t2;
-                        const int rk = 0x40000000 + (p - n_tris);  // spheres after all triangles on equal distance
-                        if ((front | inside) && (t < best || (t == best && rk < rank))) { best = t; prim = p; rank = rk; back = front ? 0 : 1; }
-                    }
-                }
-            }
-        }
-        if (sp == 0) break;
-        node = top;
-        --sp;
-        top = stack[sp > 0 ? sp - 1 : 0];
-    }
-    out.t = best; out.prim = prim; out.back = back;
+    bvh_begin(s, o, d, lights, back_cull);
+    while (!bvh_step(sc, spheres, s, stack, bc, stack_overflow)) {}
+    out.t = s.best; out.prim = s.prim; out.back = s.back;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -761,13 +786,21 @@ __device__ __forceinline__ void process_ray(const DevScene& sc, const DevSphere*
             rays_out[wc.shard * wc.shard_cap + bloc] = r;
         } else cnt->overflow = 1;
     }
-    // shaded nodes enter the wave's ring in lane order
-    if (shaded && wc.L > 0) {
-        const int slot = (ring_nodes + nrank) % RING;
-        ring_a[slot] = make_float4(P.x, P.y, P.z, rough);
-        ring_b[slot] = make_float4(N.x, N.y, N.z, __int_as_float(stored ? node : 0));
+    if constexpr (RING > 0) {
+        // shaded nodes enter the wave's ring in lane order
+        if (shaded && wc.L > 0) {
+            const int slot = (ring_nodes + nrank) % RING;
+            ring_a[slot] = make_float4(P.x, P.y, P.z, rough);
+            ring_b[slot] = make_float4(N.x, N.y, N.z, __int_as_float(stored ? node : 0));
+        }
+        ring_nodes += c_n;
+    } else {
+        // no ring: ring_a / ring_b are arrays in global memory indexed by the node's position in its level
+        if (stored && wc.L > 0) {
+            ring_a[node] = make_float4(P.x, P.y, P.z, rough);
+            ring_b[node] = make_float4(N.x, N.y, N.z, 0.0f);
+        }
     }
-    ring_nodes += c_n;
 }
 
 template <bool LEVEL0>
@@ -821,11 +854,11 @@ __device__ __forceinline__ void load_ray(const DevScene& sc, const RenderParams&
 // 64-byte line, own slice of the arrays) with wave64 ballot + prefix-popcount compaction and ONE atomic
 // per counter per 64 rays.
 // ------------------------------------------------------------------------------------------------
-template <bool LEVEL0, bool BVH>
-__global__ __launch_bounds__(T3D_BLOCK, BVH ? T3D_BVH_WAVES : 4) void k_level(DevScene sc, GEO_PARAMS, RenderParams rp, int level,
+template <bool LEVEL0>
+__global__ __launch_bounds__(T3D_BLOCK, 4) void k_level(DevScene sc, GEO_PARAMS, RenderParams rp, int level,
                                                      const RayRec* __restrict__ rays_in, RayRec* __restrict__ rays_out,
                                                      NodePool pool, Counters* cnt, TraceOut out) {
-    constexpr int RING = BVH ? T3D_RING_BVH : T3D_RING;
+    constexpr int RING = T3D_RING;
     __shared__ float4 ring_a_all[T3D_WAVES][RING];  // P.xyz, roughness
     __shared__ float4 ring_b_all[T3D_WAVES][RING];  // unit normal, int bits: node index within the level
     WaveCtx wc;
@@ -855,15 +888,12 @@ __global__ __launch_bounds__(T3D_BLOCK, BVH ? T3D_BVH_WAVES : 4) void k_level(De
     const int cs = n_in > 64 * resident ? 128 : (n_in > 32 * resident ? 64 : 32);
     int ring_nodes = 0;  // nodes appended to the ring so far      (wave-uniform)
     int items_done = 0;  // (node, light) pairs already traced     (wave-uniform)
-    BvhCount bc{0, 0, 0};
     const float inv_L = 1.0f / (float)(L > 0 ? L : 1);
     for (;;) {
         const int pending = ring_nodes * L - items_done;
         const bool more = (long long)chunk * cs < n_in;
-        // nodes whose pairs are all done leave the ring; the next trace round adds up to 128, which must fit
-        // (only the smaller ring of the LBVH kernels can fill up: 256 entries always hold 127 pending + 128 new nodes)
-        const bool ring_full = RING < 256 && L > 0 && (ring_nodes - items_done / L) + 128 > RING;
-        if (pending >= 128 || ((!more || ring_full) && pending > 0)) {
+        // nodes whose pairs are all done leave the ring: its 256 entries always hold 127 pending + 128 new nodes
+        if (pending >= 128 || (!more && pending > 0)) {
             // ---------------- shadow round: pairs items_done + lane and items_done + 64 + lane ----------------
             const int item0 = items_done + wc.lane, item1 = item0 + 64;
             const bool run0 = item0 < ring_nodes * L, run1 = item1 < ring_nodes * L;
@@ -878,12 +908,7 @@ __global__ __launch_bounds__(T3D_BLOCK, BVH ? T3D_BVH_WAVES : 4) void k_level(De
             const ShadowRay s0 = shadow_ray(sc, ring_a[nd0 % RING], rb0, l0);
             const ShadowRay s1 = shadow_ray(sc, ring_a[nd1 % RING], rb1, l1);
             Hit h0, h1;
-            if constexpr (BVH) {
-                bvh_closest(sc, spheres, s0.start, s0.Ld, run0, true, false, h0, bc, &cnt->bvh_stack_overflow);
-                bvh_closest(sc, spheres, s1.start, s1.Ld, run1, true, false, h1, bc, &cnt->bvh_stack_overflow);
-            } else {
-                closest_hit2<false, true>(GEO_ARGS, sc.geo, s0.start, s0.Ld, s1.start, s1.Ld, true, false, false, h0, h1);
-            }
+            closest_hit2<false, true>(GEO_ARGS, sc.geo, s0.start, s0.Ld, s1.start, s1.Ld, true, false, false, h0, h1);
             const float I0 = shadow_intensity(sc, spheres, s0, h0), I1 = shadow_intensity(sc, spheres, s1, h1);
             if (run0) pool.li[(wc.node_base + (size_t)__float_as_int(rb0.w)) * L + l0] = I0;
             if (run1) pool.li[(wc.node_base + (size_t)__float_as_int(rb1.w)) * L + l1] = I1;
@@ -895,26 +920,9 @@ __global__ __launch_bounds__(T3D_BLOCK, BVH ? T3D_BVH_WAVES : 4) void k_level(De
             load_ray<LEVEL0>(sc, rp, rays_in, chunk * cs + 64 + wc.lane, cs == 128 ? n_in : 0, queue_base, in1);
             const bool lights = LEVEL0 ? (rp.lights != 0) : true;
             Hit h0, h1;  // back faces culled iff ray.ior == 1 (T3DR.py:961)
-            if constexpr (BVH) {
-                bvh_closest(sc, spheres, in0.o, in0.d, in0.active, lights, in0.ior == 1.0f, h0, bc, &cnt->bvh_stack_overflow);
-                bvh_closest(sc, spheres, in1.o, in1.d, in1.active, lights, in1.ior == 1.0f, h1, bc, &cnt->bvh_stack_overflow);
-            } else {
-                closest_hit2<LEVEL0>(GEO_ARGS, sc.geo, in0.o, in0.d, in1.o, in1.d, lights, in0.ior == 1.0f, in1.ior == 1.0f, h0, h1);
-            }
-            if constexpr (BVH) {
-                // The traversal is bound by memory latency, so registers are worth more as extra waves: the rays are
-                // read again for the classification instead of being kept live across the traversal (the empty asm
-                // makes the index opaque, otherwise the compiler merges the two reads).
-                int idx0 = chunk * cs + wc.lane, idx1 = idx0 + 64;
-                asm volatile("" : "+v"(idx0), "+v"(idx1));
-                load_ray<LEVEL0>(sc, rp, rays_in, idx0, wc.lane < cs ? n_in : 0, queue_base, in0);
-                process_ray<LEVEL0, RING>(sc, spheres, rp, wc, in0, h0, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes);
-                load_ray<LEVEL0>(sc, rp, rays_in, idx1, cs == 128 ? n_in : 0, queue_base, in1);
-                process_ray<LEVEL0, RING>(sc, spheres, rp, wc, in1, h1, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes);
-            } else {
-                process_ray<LEVEL0, RING>(sc, spheres, rp, wc, in0, h0, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes);
-                process_ray<LEVEL0, RING>(sc, spheres, rp, wc, in1, h1, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes);
-            }
+            closest_hit2<LEVEL0>(GEO_ARGS, sc.geo, in0.o, in0.d, in1.o, in1.d, lights, in0.ior == 1.0f, in1.ior == 1.0f, h0, h1);
+            process_ray<LEVEL0, RING>(sc, spheres, rp, wc, in0, h0, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes);
+            process_ray<LEVEL0, RING>(sc, spheres, rp, wc, in1, h1, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes);
             chunk += chunk_step;
             // the ring is private to this wave; LDS operations of one wave complete in order, the fences
             // only stop the compiler from moving the next round's reads above these writes
@@ -925,18 +933,166 @@ __global__ __launch_bounds__(T3D_BLOCK, BVH ? T3D_BVH_WAVES : 4) void k_level(De
             break;
         }
     }
-    if constexpr (BVH) {
-        // traversal statistics: wave sum, one atomic per counter on the wave's own counter line
-        unsigned long long a = bc.nodes, b = bc.tris, c = bc.spheres;
-        for (int off = 32; off > 0; off >>= 1) {
-            a += __shfl_xor(a, off); b += __shfl_xor(b, off); c += __shfl_xor(c, off);
-        }
-        if (wc.lane == 0) {
-            atomicAdd(&cnt->bvh_stat[wc.shard][0], a);
-            atomicAdd(&cnt->bvh_stat[wc.shard][1], b);
-            atomicAdd(&cnt->bvh_stat[wc.shard][2], c);
-        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LBVH path: one tree level = three launches.
+//   k_bvh_trace    closest hit of every ray of the level -> hits[]
+//   k_bvh_process  classification, child rays, node records (process_ray) from the stored hits; the shading
+//                  inputs of every new node (hit point, normal, roughness) go to src_a / src_b
+//   k_bvh_shadow   closest hit of the shadow ray of every (node, light) pair -> li[node][light]
+// Rays of one wave need very different numbers of traversal steps, and a wave lasts as long as its slowest lane.
+// The two traversal kernels therefore never wait for a whole batch: every wave owns a fixed, interleaved share of
+// the level's rays (64-ray chunks w0, w0 + W, ...) and hands the next ray of that share to a lane as soon as
+// the lane's ray is finished.  Refills are collective (ballot + prefix count, no atomics) and happen once
+// T3D_REFILL_IDLE lanes are idle, so that the ray set-up is not run for one lane at a time.
+// ------------------------------------------------------------------------------------------------
+#ifndef T3D_REFILL_IDLE
+#define T3D_REFILL_IDLE 12
+#endif
+
+// The wave's k-th ray (k counts the rays handed out so far) -> index in the level's list
+__device__ __forceinline__ long long feed_index(int k, int w0, int W) { return ((long long)(k >> 6) * W + w0) * 64 + (k & 63); }
+
+__device__ __forceinline__ void bvh_stats_flush(const BvhCount& bc, Counters* cnt, int lane, int shard) {
+    // traversal statistics: wave sum, one atomic per counter on the wave's own counter line
+    unsigned long long a = bc.nodes, b = bc.tris, c = bc.spheres;
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_xor(a, off); b += __shfl_xor(b, off); c += __shfl_xor(c, off);
     }
+    if (lane == 0) {
+        atomicAdd(&cnt->bvh_stat[shard][0], a);
+        atomicAdd(&cnt->bvh_stat[shard][1], b);
+        atomicAdd(&cnt->bvh_stat[shard][2], c);
+    }
+}
+
+template <bool LEVEL0>
+__global__ __launch_bounds__(T3D_BLOCK, T3D_BVH_WAVES) void k_bvh_trace(DevScene sc, const DevSphere* __restrict__ spheres, RenderParams rp,
+                                                                         int level, const RayRec* __restrict__ rays_in,
+                                                                         uint2* __restrict__ hits, Counters* cnt) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const int gw = blockIdx.x * T3D_WAVES + (threadIdx.x >> 6);
+    const int nw = gridDim.x * T3D_WAVES;  // multiple of T3D_SHARDS (host guarantees)
+    const int shard = gw % T3D_SHARDS;
+    const int shard_cap = rp.cap / T3D_SHARDS;
+    const int n_in = LEVEL0 ? rp.n0 : min(cnt->n_rays[level][shard].v, shard_cap);
+    const int queue_base = shard * shard_cap;
+    const int w0 = LEVEL0 ? gw : gw / T3D_SHARDS, W = LEVEL0 ? nw : nw / T3D_SHARDS;
+    const bool lights = LEVEL0 ? (rp.lights != 0) : true;
+    BvhLane st;
+    int stack[T3D_BVH_STACK];
+    BvhCount bc{0, 0, 0};
+    bool have = false;     // a ray is in flight in this lane
+    bool pending = false;  // a finished ray's result is still in st
+    int mine = 0;          // where this lane's result goes
+    int k = 0;             // rays of this wave's share handed out so far (wave-uniform)
+    for (;;) {
+        const int n_idle = __popcll(__ballot(!have));
+        const bool more = feed_index(k, w0, W) < n_in;
+        if ((more && n_idle >= T3D_REFILL_IDLE) || n_idle == 64) {
+            // service point, shared by all idle lanes: results out, next rays in
+            const unsigned long long idle = __ballot(!have);
+            if (pending) {
+                hits[mine] = make_uint2(__float_as_uint(st.best) | ((uint32_t)st.back << 31), (uint32_t)st.prim);
+                pending = false;
+            }
+            if (!more) break;  // all 64 lanes idle and nothing left to hand out
+            const long long idx = feed_index(k + __popcll(idle & lt_mask), w0, W);
+            if (!have && idx < n_in) {
+                RayIn in;
+                load_ray<LEVEL0>(sc, rp, rays_in, (int)idx, n_in, queue_base, in);
+                mine = in.i;
+                bvh_begin(st, in.o, in.d, lights, in.ior == 1.0f);  // back faces culled iff ray.ior == 1 (T3DR.py:961)
+                have = true;
+            }
+            k += n_idle;
+        }
+        if (have && bvh_step(sc, spheres, st, stack, bc, &cnt->bvh_stack_overflow)) { have = false; pending = true; }
+    }
+    bvh_stats_flush(bc, cnt, lane, shard);
+}
+
+template <bool LEVEL0>
+__global__ __launch_bounds__(T3D_BLOCK) void k_bvh_process(DevScene sc, const DevSphere* __restrict__ spheres, RenderParams rp, int level,
+                                                           const RayRec* __restrict__ rays_in, RayRec* __restrict__ rays_out,
+                                                           const uint2* __restrict__ hits, NodePool pool, Counters* cnt, TraceOut out,
+                                                           float4* __restrict__ src_a, float4* __restrict__ src_b) {
+    WaveCtx wc;
+    wc.lane = threadIdx.x & 63; wc.wid = threadIdx.x >> 6;
+    wc.lt_mask = (1ull << wc.lane) - 1ull;
+    const int gw = blockIdx.x * T3D_WAVES + wc.wid;
+    const int nw = gridDim.x * T3D_WAVES;
+    wc.shard = gw % T3D_SHARDS;
+    wc.shard_cap = rp.cap / T3D_SHARDS;
+    wc.level = level;
+    wc.node_base = (size_t)level * rp.cap;
+    wc.L = sc.n_lights;
+    const int n_in = LEVEL0 ? rp.n0 : min(cnt->n_rays[level][wc.shard].v, wc.shard_cap);
+    const int queue_base = wc.shard * wc.shard_cap;
+    const int chunk_step = LEVEL0 ? nw : nw / T3D_SHARDS;
+    int unused = 0;
+    for (int chunk = LEVEL0 ? gw : gw / T3D_SHARDS; (long long)chunk * 64 < n_in; chunk += chunk_step) {
+        RayIn in;
+        load_ray<LEVEL0>(sc, rp, rays_in, chunk * 64 + wc.lane, n_in, queue_base, in);
+        Hit h;
+        h.t = __builtin_inff(); h.prim = -1; h.back = 0;
+        if (in.active) {
+            const uint2 r = hits[in.i];
+            h.t = __uint_as_float(r.x & 0x7fffffffu); h.back = (int)(r.x >> 31); h.prim = (int)r.y;
+        }
+        process_ray<LEVEL0, 0>(sc, spheres, rp, wc, in, h, rays_out, pool, cnt, out, src_a, src_b, unused);
+    }
+}
+
+__global__ __launch_bounds__(T3D_BLOCK, T3D_BVH_WAVES) void k_bvh_shadow(DevScene sc, const DevSphere* __restrict__ spheres, RenderParams rp,
+                                                                          int level, const float4* __restrict__ src_a,
+                                                                          const float4* __restrict__ src_b, NodePool pool, Counters* cnt) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const int gw = blockIdx.x * T3D_WAVES + (threadIdx.x >> 6);
+    const int nw = gridDim.x * T3D_WAVES;
+    const int shard = gw % T3D_SHARDS;
+    const int shard_cap = rp.cap / T3D_SHARDS;
+    const int L = sc.n_lights;
+    const long long n_in = (long long)min(cnt->n_nodes[level][shard].v, shard_cap) * L;  // (node, light) pairs of this shard
+    const int w0 = gw / T3D_SHARDS, W = nw / T3D_SHARDS;
+    const size_t node_base = (size_t)level * rp.cap;
+    BvhLane st;
+    int stack[T3D_BVH_STACK];
+    BvhCount bc{0, 0, 0};
+    bool have = false, pending = false;
+    int my_node = 0, my_light = 0;
+    int k = 0;
+    for (;;) {
+        const int n_idle = __popcll(__ballot(!have));
+        const bool more = feed_index(k, w0, W) < n_in;
+        if ((more && n_idle >= T3D_REFILL_IDLE) || n_idle == 64) {
+            const unsigned long long idle = __ballot(!have);
+            if (pending) {
+                // the shading inputs are read again rather than kept in registers across the traversal
+                const ShadowRay s = shadow_ray(sc, src_a[my_node], src_b[my_node], my_light);
+                Hit h;
+                h.t = st.best; h.prim = st.prim; h.back = st.back;
+                pool.li[(node_base + (size_t)my_node) * L + my_light] = shadow_intensity(sc, spheres, s, h);
+                pending = false;
+            }
+            if (!more) break;
+            const long long idx = feed_index(k + __popcll(idle & lt_mask), w0, W);
+            if (!have && idx < n_in) {
+                const int nd = (int)(idx / L);
+                my_light = (int)(idx - (long long)nd * L);
+                my_node = shard * shard_cap + nd;
+                const ShadowRay s = shadow_ray(sc, src_a[my_node], src_b[my_node], my_light);
+                bvh_begin(st, s.start, s.Ld, true, false);
+                have = true;
+            }
+            k += n_idle;
+        }
+        if (have && bvh_step(sc, spheres, st, stack, bc, &cnt->bvh_stack_overflow)) { have = false; pending = true; }
+    }
+    bvh_stats_flush(bc, cnt, lane, shard);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1066,6 +1222,8 @@ struct t3d_ctx {
     size_t cap_alloc = 0; int levels_alloc = 0; int li_lights = 0;
     RayRec* d_rays[2] = {nullptr, nullptr};
     NodePool pool{};
+    // LBVH path only: closest hit of every ray of the current level; shading inputs of its new nodes
+    uint2* d_hits = nullptr; float4* d_src_a = nullptr; float4* d_src_b = nullptr;
     size_t n0_alloc = 0;
     float4* d_sample_color = nullptr;
     Counters* d_cnt = nullptr;
@@ -1141,6 +1299,8 @@ static void free_scene(t3d_ctx* c) {
 static void free_work(t3d_ctx* c) {
     hipFree(c->d_rays[0]); hipFree(c->d_rays[1]); hipFree(c->pool.parent); hipFree(c->pool.c);
     hipFree(c->pool.d); hipFree(c->pool.dbg); hipFree(c->pool.li);
+    hipFree(c->d_hits); hipFree(c->d_src_a); hipFree(c->d_src_b);
+    c->d_hits = nullptr; c->d_src_a = c->d_src_b = nullptr;
     c->d_rays[0] = c->d_rays[1] = nullptr; c->pool = NodePool{}; c->cap_alloc = 0; c->levels_alloc = 0;
 }
 
@@ -1404,7 +1564,8 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
 }
 
 static int ensure_work(t3d_ctx* c, size_t cap, int levels, size_t n0, bool dbg) {
-    if (cap > c->cap_alloc || levels > c->levels_alloc || (dbg && !c->pool.dbg) || c->sc.n_lights > c->li_lights) {
+    if (cap > c->cap_alloc || levels > c->levels_alloc || (dbg && !c->pool.dbg) || c->sc.n_lights > c->li_lights ||
+        (c->use_bvh && !c->d_hits)) {
         free_work(c);
         size_t cap2 = cap, lv = (size_t)levels;
         HIPCHK(c, hipMalloc((void**)&c->d_rays[0], sizeof(RayRec) * cap2));
@@ -1413,6 +1574,11 @@ static int ensure_work(t3d_ctx* c, size_t cap, int levels, size_t n0, bool dbg) 
         HIPCHK(c, hipMalloc((void**)&c->pool.c, sizeof(float4) * cap2 * lv));
         HIPCHK(c, hipMalloc((void**)&c->pool.d, sizeof(float4) * cap2 * lv));
         if (dbg) HIPCHK(c, hipMalloc((void**)&c->pool.dbg, sizeof(int) * cap2 * lv));
+        if (c->use_bvh) {
+            HIPCHK(c, hipMalloc((void**)&c->d_hits, sizeof(uint2) * cap2));
+            HIPCHK(c, hipMalloc((void**)&c->d_src_a, sizeof(float4) * cap2));
+            HIPCHK(c, hipMalloc((void**)&c->d_src_b, sizeof(float4) * cap2));
+        }
         HIPCHK(c, hipMalloc((void**)&c->pool.li, sizeof(float) * cap2 * lv * (size_t)(c->sc.n_lights > 0 ? c->sc.n_lights : 1)));
         c->li_lights = c->sc.n_lights;
         c->cap_alloc = cap2; c->levels_alloc = levels;
@@ -1535,20 +1701,46 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
     const int* pfirst = (const int*)c->d_plane_first;
     const float4* uv = (const float4*)c->d_tri_uv;
     const DevSphere* sph = (const DevSphere*)c->d_spheres;
-    auto kl0 = c->use_bvh ? k_level<true, true> : k_level<true, false>;
-    auto kln = c->use_bvh ? k_level<false, true> : k_level<false, false>;
+    // the traversal kernels of the LBVH path keep as many waves as the device holds, each with a fixed share of the rays
+    auto resident_blocks_for = [&](size_t n) {
+        size_t b = (n + T3D_BLOCK - 1) / T3D_BLOCK, mx = (size_t)c->n_sm * T3D_BVH_WAVES;
+        b = b > mx ? mx : b;
+        b = (b + grid_unit - 1) / grid_unit * grid_unit;
+        return (int)b;
+    };
     HIPCHK(c, tick());  // ev[0]: start of the call
     for (int d = 0; d < levels; ++d) {
         RayRec* in = c->d_rays[d & 1];
         RayRec* outq = c->d_rays[(d + 1) & 1];
-        if (d == 0)
-            hipLaunchKernelGGL(kl0, dim3(trace_blocks_for(n0)), dim3(T3D_BLOCK), 0, st, c->sc, planes,
-                               pfirst, uv, sph, rp, d, in, outq, c->pool, c->d_cnt, out);
-        else
-            hipLaunchKernelGGL(kln, dim3(single ? (int)grid_unit : trace_blocks_for(c->cap_alloc)),
-                               dim3(T3D_BLOCK), 0, st, c->sc, planes, pfirst, uv, sph, rp, d, in, outq, c->pool, c->d_cnt, out);
-        if (c->timing) HIPCHK(c, tick());  // ev[1 + d]: k_level(d) done
-        launches += 1;
+        const int grid_n = single ? (int)grid_unit : trace_blocks_for(d == 0 ? n0 : c->cap_alloc);
+        if (c->use_bvh) {
+            const int grid_r = single ? (int)grid_unit : resident_blocks_for(d == 0 ? n0 : c->cap_alloc);
+            if (d == 0) {
+                hipLaunchKernelGGL(k_bvh_trace<true>, dim3(grid_r), dim3(T3D_BLOCK), 0, st, c->sc, sph, rp, d, in, c->d_hits, c->d_cnt);
+                hipLaunchKernelGGL(k_bvh_process<true>, dim3(grid_n), dim3(T3D_BLOCK), 0, st, c->sc, sph, rp, d, in, outq, c->d_hits, c->pool,
+                                   c->d_cnt, out, c->d_src_a, c->d_src_b);
+            } else {
+                hipLaunchKernelGGL(k_bvh_trace<false>, dim3(grid_r), dim3(T3D_BLOCK), 0, st, c->sc, sph, rp, d, in, c->d_hits, c->d_cnt);
+                hipLaunchKernelGGL(k_bvh_process<false>, dim3(grid_n), dim3(T3D_BLOCK), 0, st, c->sc, sph, rp, d, in, outq, c->d_hits, c->pool,
+                                   c->d_cnt, out, c->d_src_a, c->d_src_b);
+            }
+            launches += 2;
+            if (c->sc.n_lights > 0) {
+                const size_t pairs = (d == 0 ? n0 : c->cap_alloc) * (size_t)c->sc.n_lights;
+                hipLaunchKernelGGL(k_bvh_shadow, dim3(single ? (int)grid_unit : resident_blocks_for(pairs)), dim3(T3D_BLOCK), 0, st, c->sc, sph, rp,
+                                   d, c->d_src_a, c->d_src_b, c->pool, c->d_cnt);
+                launches += 1;
+            }
+        } else {
+            if (d == 0)
+                hipLaunchKernelGGL(k_level<true>, dim3(grid_n), dim3(T3D_BLOCK), 0, st, c->sc, planes, pfirst, uv, sph, rp, d, in, outq,
+                                   c->pool, c->d_cnt, out);
+            else
+                hipLaunchKernelGGL(k_level<false>, dim3(grid_n), dim3(T3D_BLOCK), 0, st, c->sc, planes, pfirst, uv, sph, rp, d, in, outq,
+                                   c->pool, c->d_cnt, out);
+            launches += 1;
+        }
+        if (c->timing) HIPCHK(c, tick());  // ev[1 + d]: level d traced
     }
     for (int d = levels - 1; d >= 0; --d) {
         hipLaunchKernelGGL(k_resolve, dim3(single ? (int)grid_unit : trace_blocks_for(c->cap_alloc)), dim3(T3D_BLOCK), 0, st, c->sc, rp, d, c->pool, c->d_cnt,
@@ -1585,7 +1777,8 @@ extern "C" int t3d_render_rows_device(t3d_ctx* c, const t3d_opts* o, int row0, i
     const int S = o->bounces > 1 ? o->samples : 1;
     const int levels = o->bounces + 1;
     // rows per band: the optimistic working set (capacity factor 2 per level) must fit the budget
-    const size_t per_sample = (size_t)2 * (2 * sizeof(RayRec) + (size_t)levels * (36 + 4 * (size_t)(c->sc.n_lights > 0 ? c->sc.n_lights : 1))) + sizeof(float4);
+    const size_t per_sample = (size_t)2 * (2 * sizeof(RayRec) + (c->use_bvh ? sizeof(uint2) + 2 * sizeof(float4) : 0) +
+                                           (size_t)levels * (36 + 4 * (size_t)(c->sc.n_lights > 0 ? c->sc.n_lights : 1))) + sizeof(float4);
     size_t max_samples = c->mem_budget / per_sample;
     size_t max_idx = (size_t)0x7FFFFFF0 / ((size_t)levels * 2);
     if (max_samples > max_idx) max_samples = max_idx;

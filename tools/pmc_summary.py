@@ -19,11 +19,12 @@ for k, cs in acc.items():
 if "--traffic-json" in sys.argv:
     import json
     out = sys.argv[sys.argv.index("--traffic-json") + 1]
+    workload = sys.argv[sys.argv.index("--workload") + 1] if "--workload" in sys.argv else "cornell_1080p_b4"
     f = [x for k, cs in acc.items() if k.startswith("k_level") for x in cs.get("FETCH_SIZE", [])]
     w = [x for k, cs in acc.items() if k.startswith("k_level") for x in cs.get("WRITE_SIZE", [])]
     if f and w:
         fk, wk = sum(f) / len(f), sum(w) / len(w)
-        json.dump({"kernel": "k_level", "workload": "cornell_1080p_b4", "fetch_size_kib_per_launch": round(fk, 1),
+        json.dump({"kernel": "k_level", "workload": workload, "fetch_size_kib_per_launch": round(fk, 1),
                    "write_size_kib_per_launch": round(wk, 1), "fetch_correction": 2.0,
                    "hbm_bytes_per_launch": int((2.0 * fk + wk) * 1024), "launches_sampled": [len(f), len(w)]},
                   open(out, "w"), indent=1)

@@ -15,7 +15,7 @@ print(f"{'kernel':28s} {'calls':>6s} {'total_us':>10s} {'avg_us':>9s} vgpr sgpr 
 for k, t in sorted(tot.items(), key=lambda kv: -kv[1][1]):
     print(f"{k:28s} {t[0]:6d} {t[1]/1e3:10.1f} {t[1]/t[0]/1e3:9.2f} {t[2]:>4s} {t[3]:>4s} {t[4]:>3s} {t[5]:>3s}")
 # last frame = launches after the last k_trace<true>
-idx = max(i for i, r in enumerate(rows) if short(r["Kernel_Name"]).startswith(("k_trace<true", "k_level<true")))
+idx = max(i for i, r in enumerate(rows) if short(r["Kernel_Name"]).startswith(("k_trace<true", "k_level<true", "k_bvh_trace<true")))
 t0 = int(rows[idx]["Start_Timestamp"])
 print("\nlast frame launch sequence (start offset us, duration us, grid):")
 for r in rows[idx:]:

@@ -28,3 +28,5 @@ for n in ([int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]):
     ctx.set_timing(True)
     print(f"ranks {n}: rows {rows}  {ms:.4f} ms/frame per rank  queries {st['queries']}  -> speedup bound {0:.2f}" if n == 1 else
           f"ranks {n}: rows {rows}  {ms:.4f} ms/frame per rank  queries {st['queries']}")
+    print("   k_level ms per level", [round(x, 4) for x in st["level_ms"][:opt["bounces"] + 1]], "resolve+finish ms", round(st["ms_resolve"], 4),
+          "rays per level", st["level_rays"][:opt["bounces"] + 1], "nodes", st["level_nodes"][:opt["bounces"] + 1])
