@@ -185,10 +185,9 @@ def main():
             line["roofline"]["traffic"] = tr[0]["hbm_bytes_per_launch"]
             line["roofline"]["traffic_source"] = "profiles/" + tr[1]
         if last["aabb_tests"] > 0:
-            # LBVH traversal: HBM roofline.  Algorithmic bytes: 128 B per node record visited (four boxes and links),
-            # 64 B per triangle test (one leaf record: plane row, two barycentric rows, order index), 32 B per
-            # sphere test.
-            nbytes = 128.0 * (last["aabb_tests"] / 4) + 64.0 * last["tri_tests"] + 32.0 * last["sphere_tests"]
+            # LBVH traversal: memory roofline.  Algorithmic bytes: 64 B per node record visited (four quantised boxes
+            # and their links), 64 B per triangle or sphere test (one leaf record).
+            nbytes = 64.0 * (last["aabb_tests"] / 4) + 64.0 * last["tri_tests"] + 64.0 * last["sphere_tests"]
             gbs = nbytes / level_s / 1e9 if level_s > 0 else 0.0
             line["roofline"] = {"bound": "hbm", "kernel": "k_level (LBVH traversal)", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,

@@ -97,9 +97,9 @@ struct DevGeo {
     float box_lo[3], box_hi[3];  // bounds of every triangle and sphere, padded outward
 };
 struct DevBvh {
-    const float4* nodes;   // [n_prims - 1] x 8 rows, see t3d_lbvh.h; null when the scene is traced by brute force
-    const float4* tri_ab;  // [4T] per triangle one 64-byte record: (n.xyz, -n.v0), (a.xyz, aw), (b.xyz, bw) with
-                           // u = a.P + aw, v = b.P + bw, and (-, -, -, index in the scene's object / face order as int bits)
+    const float4* nodes;   // [n_prims - 1] x 4 rows, see t3d_lbvh.h; null when the scene is traced by brute force
+    const float4* leaves;  // [n_prims] x 4 rows in sorted order, see k_lbvh_leaves; triangles: (n.xyz, -n.v0), (a.xyz, aw),
+                           // (b.xyz, bw) with u = a.P + aw, v = b.P + bw
     int n_prims;
 };
 struct DevScene {
@@ -394,7 +394,7 @@ __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0
 #define T3D_BVH_STACK 96
 #endif
 #ifndef T3D_BVH_WAVES
-#define T3D_BVH_WAVES 5   // waves per SIMD the traversal kernels are compiled for
+#define T3D_BVH_WAVES 6   // waves per SIMD the traversal kernels are compiled for
 #endif
 struct BvhCount {
     uint32_t nodes, tris, spheres;
@@ -427,30 +427,35 @@ __device__ __forceinline__ void bvh_begin(BvhLane& s, V3 o, V3 d, bool lights, b
 
 // One step: a node record (four slab tests, entered slots pushed far to near, nearest descended into) or a leaf
 // (one triangle or sphere).  Returns true when nothing is left on the stack.
-__device__ __forceinline__ bool bvh_step(const DevScene& sc, const DevSphere* __restrict__ spheres, BvhLane& s, int (&stack)[T3D_BVH_STACK],
-                                         BvhCount& bc, int* stack_overflow) {
-    const float4* __restrict__ nodes = sc.bvh.nodes;
-    const float4* __restrict__ tri_ab = sc.bvh.tri_ab;
-    const int n_tris = sc.n_tris;
+__device__ __forceinline__ bool bvh_step(const DevScene& sc, BvhLane& s, int (&stack)[T3D_BVH_STACK], BvhCount& bc, int* stack_overflow) {
     const V3 o = s.o, d = s.d, inv = s.inv, oi = s.oi;
     if (s.node >= 0) {
-        const float4* __restrict__ rec = nodes + 8 * (size_t)s.node;
-        const float4 lx = rec[0], ly = rec[1], lz = rec[2], hx = rec[3], hy = rec[4], hz = rec[5], lk = rec[6];
+        const float4* __restrict__ rec = sc.bvh.nodes + 4 * (size_t)s.node;
+        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
         bc.nodes++;
-        // slabs of the four slots: t = (plane - o) / d = plane * inv + oi; a slot is entered while its interval
-        // reaches the best distance so far (<=: equal distances must all be seen); empty slots never are
+        const uint32_t meta = __float_as_uint(r0.w);
+        // plane = origin + q * step, so t = (plane - o) / d = q * (step * inv) + (origin * inv + oi)
+        const float sx = __uint_as_float((meta & 255u) << 23) * inv.x, sy = __uint_as_float(((meta >> 8) & 255u) << 23) * inv.y,
+                    sz = __uint_as_float(((meta >> 16) & 255u) << 23) * inv.z;
+        const float cx = fmaf(r0.x, inv.x, oi.x), cy = fmaf(r0.y, inv.y, oi.y), cz = fmaf(r0.z, inv.z, oi.z);
+        const uint32_t qlx = __float_as_uint(r1.x), qhx = __float_as_uint(r1.y), qly = __float_as_uint(r1.z), qhy = __float_as_uint(r1.w);
+        const uint32_t qlz = __float_as_uint(r2.x), qhz = __float_as_uint(r2.y);
+        const int base01 = __float_as_int(r2.z), base23 = __float_as_int(r2.w);
+        // a slot is entered while its slab interval reaches the best distance so far (<=: equal distances must all
+        // be seen); empty slots never are
         float tn[4];
-        int ln[4] = {__float_as_int(lk.x), __float_as_int(lk.y), __float_as_int(lk.z), __float_as_int(lk.w)};
-        const float lxa[4] = {lx.x, lx.y, lx.z, lx.w}, lya[4] = {ly.x, ly.y, ly.z, ly.w}, lza[4] = {lz.x, lz.y, lz.z, lz.w};
-        const float hxa[4] = {hx.x, hx.y, hx.z, hx.w}, hya[4] = {hy.x, hy.y, hy.z, hy.w}, hza[4] = {hz.x, hz.y, hz.z, hz.w};
+        int ln[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float ax = fmaf(lxa[k], inv.x, oi.x), bx = fmaf(hxa[k], inv.x, oi.x);
-            const float ay = fmaf(lya[k], inv.y, oi.y), by = fmaf(hya[k], inv.y, oi.y);
-            const float az = fmaf(lza[k], inv.z, oi.z), bz = fmaf(hza[k], inv.z, oi.z);
+            const float ax = fmaf((float)((qlx >> (8 * k)) & 255u), sx, cx), bx = fmaf((float)((qhx >> (8 * k)) & 255u), sx, cx);
+            const float ay = fmaf((float)((qly >> (8 * k)) & 255u), sy, cy), by = fmaf((float)((qhy >> (8 * k)) & 255u), sy, cy);
+            const float az = fmaf((float)((qlz >> (8 * k)) & 255u), sz, cz), bz = fmaf((float)((qhz >> (8 * k)) & 255u), sz, cz);
             const float near = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
             const float far = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), s.best)) * 1.0000004f;
-            tn[k] = near <= far ? near : __builtin_inff();   // +inf: not entered
+            const uint32_t kind = (meta >> (24 + 2 * k)) & 3u;
+            tn[k] = (near <= far && kind != 0u) ? near : __builtin_inff();   // +inf: not entered
+            const int number = (k < 2 ? base01 : base23) + (k & 1);
+            ln[k] = kind == 2u ? ~number : number;                           // leaves travel as negative links
         }
         // order the slots by entry distance (5 compare-exchanges), nearest first
         auto cswap = [&](int a, int b) {
@@ -469,13 +474,13 @@ __device__ __forceinline__ bool bvh_step(const DevScene& sc, const DevSphere* __
         }
         if (tn[0] < __builtin_inff()) { s.node = ln[0]; return false; }
     } else {
-        const int p = ~s.node;
-        if (p < n_tris) {
+        // all rows are requested at once: one memory latency per leaf instead of two on the hit path
+        const float4* __restrict__ rec = sc.bvh.leaves + 4 * (size_t)(~s.node);
+        const float4 rn = rec[0], ra = rec[1], rb = rec[2], rm = rec[3];
+        const int p = __float_as_int(rm.x), rk = __float_as_int(rm.w);  // rk: place in the scene's object / face order, spheres last
+        if (__float_as_int(rm.y) == 0) {
             // getFaceCollision (T3DR.py:624-651) for one triangle
             bc.tris++;
-            // all rows are requested at once: one memory latency per leaf instead of two on the hit path
-            const float4 rn = tri_ab[4 * (size_t)p], ra = tri_ab[4 * (size_t)p + 1], rb = tri_ab[4 * (size_t)p + 2];
-            const float4 rm = tri_ab[4 * (size_t)p + 3];
             const float dn = fmaf(rn.z, d.z, fmaf(rn.y, d.y, rn.x * d.x));
             if (fabsf(dn) >= 1e-6f && (!s.back_cull || dn < 0.0f)) {
                 const float q = fmaf(rn.z, o.z, fmaf(rn.y, o.y, fmaf(rn.x, o.x, rn.w)));
@@ -486,27 +491,25 @@ __device__ __forceinline__ bool bvh_step(const DevScene& sc, const DevSphere* __
                     const float v = fmaf(rb.z, P.z, fmaf(rb.y, P.y, fmaf(rb.x, P.x, rb.w)));
                     const float w = (1.0f - u) - v;
                     if (fminf(fminf(u, v), w) > 0.0f) {
-                        const int rk = __float_as_int(rm.w);  // index in the scene's object / face order
                         if (t < s.best || rk < s.rank) { s.best = t; s.prim = p; s.rank = rk; s.back = 0; }
                     }
                 }
             }
         } else {
             // getSphereCollision (T3DR.py:572-598)
-            const DevSphere sp = spheres[p - n_tris];
-            if (!sp.is_light || s.lights) {
+            const int is_light = __float_as_int(ra.x);
+            if (!is_light || s.lights) {
                 bc.spheres++;
-                const V3 Lv = mk(o.x - sp.cx, o.y - sp.cy, o.z - sp.cz);
+                const V3 Lv = mk(o.x - rn.x, o.y - rn.y, o.z - rn.z);
                 const float b = dot(Lv, d);
                 const V3 qv = madd(Lv, d, -b);  // L - b d: see closest_hit2
-                const float disc = sp.r2 - dot(qv, qv);
+                const float disc = rn.w - dot(qv, qv);
                 if (disc >= 0.0f) {
                     const float root = __builtin_amdgcn_sqrtf(disc);
                     const float t1 = -b - root, t2 = -b + root;
                     const bool front = t1 > 0.0f;
-                    const bool inside = (!front) & (t2 > 0.0f) & (!s.back_cull) & (sp.is_light == 0);
+                    const bool inside = (!front) & (t2 > 0.0f) & (!s.back_cull) & (is_light == 0);
                     const float t = front ? t1 : t2;
-                    const int rk = 0x40000000 + (p - n_tris);  // spheres after all triangles on equal distance
                     if ((front | inside) && (t < s.best || (t == s.best && rk < s.rank))) { s.best = t; s.prim = p; s.rank = rk; s.back = front ? 0 : 1; }
                 }
             }
@@ -527,7 +530,7 @@ __device__ __forceinline__ void bvh_closest(const DevScene& sc, const DevSphere*
     BvhLane s;
     int stack[T3D_BVH_STACK];
     bvh_begin(s, o, d, lights, back_cull);
-    while (!bvh_step(sc, spheres, s, stack, bc, stack_overflow)) {}
+    while (!bvh_step(sc, s, stack, bc, stack_overflow)) {}
     out.t = s.best; out.prim = s.prim; out.back = s.back;
 }
 
@@ -948,7 +951,7 @@ __global__ __launch_bounds__(T3D_BLOCK, 4) void k_level(DevScene sc, GEO_PARAMS,
 // T3D_REFILL_IDLE lanes are idle, so that the ray set-up is not run for one lane at a time.
 // ------------------------------------------------------------------------------------------------
 #ifndef T3D_REFILL_IDLE
-#define T3D_REFILL_IDLE 12
+#define T3D_REFILL_IDLE 24
 #endif
 
 // The wave's k-th ray (k counts the rays handed out so far) -> index in the level's list
@@ -1009,7 +1012,7 @@ __global__ __launch_bounds__(T3D_BLOCK, T3D_BVH_WAVES) void k_bvh_trace(DevScene
             }
             k += n_idle;
         }
-        if (have && bvh_step(sc, spheres, st, stack, bc, &cnt->bvh_stack_overflow)) { have = false; pending = true; }
+        if (have && bvh_step(sc, st, stack, bc, &cnt->bvh_stack_overflow)) { have = false; pending = true; }
     }
     bvh_stats_flush(bc, cnt, lane, shard);
 }
@@ -1090,7 +1093,7 @@ __global__ __launch_bounds__(T3D_BLOCK, T3D_BVH_WAVES) void k_bvh_shadow(DevScen
             }
             k += n_idle;
         }
-        if (have && bvh_step(sc, spheres, st, stack, bc, &cnt->bvh_stack_overflow)) { have = false; pending = true; }
+        if (have && bvh_step(sc, st, stack, bc, &cnt->bvh_stack_overflow)) { have = false; pending = true; }
     }
     bvh_stats_flush(bc, cnt, lane, shard);
 }
@@ -1212,7 +1215,7 @@ struct t3d_ctx {
     // scene buffers
     DevScene sc{};
     void* d_planes = nullptr; void* d_plane_first = nullptr; void* d_tri_uv = nullptr; void* d_tri_n = nullptr;
-    void* d_bvh_nodes = nullptr; void* d_tri_ab = nullptr;
+    void* d_bvh_nodes = nullptr; void* d_bvh_leaves = nullptr;
     int accel = T3D_ACCEL_AUTO;   // t3d_set_accel
     bool use_bvh = false;         // the uploaded scene is traced through the LBVH
     void* d_tri_meta = nullptr; void* d_spheres = nullptr; void* d_lights = nullptr;
@@ -1289,7 +1292,7 @@ extern "C" int t3d_create(int device, t3d_ctx** out) {
 
 static void free_scene(t3d_ctx* c) {
     hipFree(c->d_planes); hipFree(c->d_plane_first); hipFree(c->d_tri_uv); hipFree(c->d_tri_n);
-    hipFree(c->d_bvh_nodes); hipFree(c->d_tri_ab); c->d_bvh_nodes = c->d_tri_ab = nullptr; c->use_bvh = false;
+    hipFree(c->d_bvh_nodes); hipFree(c->d_bvh_leaves); c->d_bvh_nodes = c->d_bvh_leaves = nullptr; c->use_bvh = false;
     hipFree(c->d_tri_meta); hipFree(c->d_spheres); hipFree(c->d_lights);
     hipFree(c->d_shaders); hipFree(c->d_obj_ior);
     c->d_planes = c->d_plane_first = c->d_tri_uv = c->d_tri_n = nullptr;
@@ -1520,16 +1523,19 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
             tri_ab[4 * (size_t)k + 2] = make_float4((float)b[0], (float)b[1], (float)b[2], -(float)(b[0] * v[0] + b[1] * v[1] + b[2] * v[2]) + 0.0f);
         }
         void* d_verts = nullptr;
-        if ((rc = upload(c, &c->d_tri_ab, tri_ab)) || (rc = upload(c, &d_verts, verts))) { hipFree(d_verts); return rc; }
+        void* d_tri_ab = nullptr;   // records in device order; the build copies them into sorted leaf order
+        if ((rc = upload(c, &d_tri_ab, tri_ab)) || (rc = upload(c, &d_verts, verts))) { hipFree(d_verts); hipFree(d_tri_ab); return rc; }
         float4* nodes = nullptr;
-        hipError_t e = lbvh_build(c->stream, (const float*)d_verts, s->n_tris, (const DevSphere*)c->d_spheres, (int)spheres.size(), &nodes);
-        hipFree(d_verts);
+        float4* leaves = nullptr;
+        hipError_t e = lbvh_build(c->stream, (const float*)d_verts, (const float4*)d_tri_ab, s->n_tris, (const DevSphere*)c->d_spheres,
+                                  (int)spheres.size(), &nodes, &leaves);
+        hipFree(d_verts); hipFree(d_tri_ab);
         if (e != hipSuccess) { c->err = std::string("t3d_upload_scene: LBVH build failed: ") + hipGetErrorString(e); return T3D_E_DEVICE; }
-        c->d_bvh_nodes = nodes;
+        c->d_bvh_nodes = nodes; c->d_bvh_leaves = leaves;
         c->use_bvh = true;
     }
     DevScene& d = c->sc;
-    d.bvh.nodes = (const float4*)c->d_bvh_nodes; d.bvh.tri_ab = (const float4*)c->d_tri_ab; d.bvh.n_prims = n_prims;
+    d.bvh.nodes = (const float4*)c->d_bvh_nodes; d.bvh.leaves = (const float4*)c->d_bvh_leaves; d.bvh.n_prims = n_prims;
     d.geo.axis_end[0] = axis_count[0]; d.geo.axis_end[1] = axis_count[0] + axis_count[1]; d.geo.axis_end[2] = (int)G;
     d.geo.n_tris = s->n_tris; d.geo.n_spheres = (int)spheres.size();
     {   // scene bounds for the camera-ray pre-test, padded outward by 1e-4 of their size

@@ -214,71 +214,116 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_refit(const int* __restrict
     }
 }
 
-// Traversal nodes, 4 wide: the record of binary node i holds the boxes and links of its GRANDchildren (a child
-// that is a leaf takes one slot itself), so one fetch decides four subtrees and a ray makes half as many dependent
-// fetches on its way down.  128 bytes, structure of arrays over the four slots:
-//   rows 0..2 = lo.x, lo.y, lo.z of slots 0..3;  rows 3..5 = hi.x, hi.y, hi.z;  row 6 = links as int bits;  row 7 unused
-// link >= 0: binary node index (whose own record is the next fetch); link < 0: leaf holding primitive ~link
-// (primitive p < n_tris: triangle p in device order; otherwise sphere p - n_tris).  Unused slots hold a box that is
-// a single point at 1e38 on every axis: its slab interval is empty for every ray (an inverted box would not do, the
-// slab test is symmetric in lo and hi).
+// Traversal nodes, 4 wide and quantised: the record of binary node i describes its GRANDchildren (a child that is
+// a leaf takes one slot itself), so one fetch decides four subtrees and a ray makes half as many dependent fetches
+// on its way down.  The traversal is bound by the number of 16-byte accesses a lane makes, not by arithmetic, so a
+// record is three rows (48 bytes used of a 64-byte stride, never straddling a cache line):
+//   row 0  origin.x, origin.y, origin.z of the record's own frame; meta = ex | ey << 8 | ez << 16 | kinds << 24
+//          (e*: biased exponent of the power-of-two grid step of the axis; kinds: 2 bits per slot, 0 empty,
+//          1 internal node, 2 leaf)
+//   row 1  lo.x, hi.x, lo.y, hi.y of the four slots, one byte per slot (slot k in bits 8k..8k+7)
+//   row 2  lo.z, hi.z the same way; base01, base23
+// A slot's box is origin + q * step, lo rounded down and hi rounded up, so it contains the exact (padded) box.
+// Links need no storage of their own: in this hierarchy the children of a node split at position g are node or
+// leaf g and node or leaf g + 1, so slots 0, 1 are base01, base01 + 1 and slots 2, 3 are base23, base23 + 1 (a child
+// that is a leaf itself: slot 0 / 2 is that leaf, slot 1 / 3 empty).  Leaves are numbered by sorted position.
 __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_pack(const int* __restrict__ vals, int n, const float4* __restrict__ prim_lo,
                                                           const float4* __restrict__ prim_hi, const int2* __restrict__ kids,
                                                           const float4* __restrict__ box_lo, const float4* __restrict__ box_hi,
                                                           float4* __restrict__ nodes) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
-    float lo[3][4], hi[3][4];
-    int link[4];
-    for (int k = 0; k < 4; ++k) {
-        for (int a = 0; a < 3; ++a) { lo[a][k] = 1e38f; hi[a][k] = 1e38f; }   // a point no ray reaches before its best hit
-        link[k] = 0;
-    }
-    int slot = 0;
-    auto put = [&](int id) {   // id: internal node (< n - 1) or leaf (n - 1 + sorted position)
+    float lo[4][3], hi[4][3];
+    int kind[4] = {0, 0, 0, 0}, base[2] = {0, 0};
+    auto put = [&](int slot, int id) -> int {   // id: internal node (< n - 1) or leaf (n - 1 + sorted position); returns its number
         float4 l, h;
-        int c;
-        if (id >= n - 1) { const int p = vals[id - (n - 1)]; l = prim_lo[p]; h = prim_hi[p]; c = ~p; }
-        else { l = box_lo[id]; h = box_hi[id]; c = id; }
-        lo[0][slot] = l.x; lo[1][slot] = l.y; lo[2][slot] = l.z;
-        hi[0][slot] = h.x; hi[1][slot] = h.y; hi[2][slot] = h.z;
-        link[slot] = c;
-        ++slot;
+        const bool leaf = id >= n - 1;
+        if (leaf) { const int p = vals[id - (n - 1)]; l = prim_lo[p]; h = prim_hi[p]; }
+        else { l = box_lo[id]; h = box_hi[id]; }
+        lo[slot][0] = l.x; lo[slot][1] = l.y; lo[slot][2] = l.z;
+        hi[slot][0] = h.x; hi[slot][1] = h.y; hi[slot][2] = h.z;
+        kind[slot] = leaf ? 2 : 1;
+        return leaf ? id - (n - 1) : id;
     };
     const int2 k = kids[i];
     const int child[2] = {k.x, k.y};
     for (int c = 0; c < 2; ++c) {
-        if (child[c] >= n - 1) put(child[c]);
-        else { const int2 g = kids[child[c]]; put(g.x); put(g.y); }
+        if (child[c] >= n - 1) base[c] = put(2 * c, child[c]);
+        else { const int2 g = kids[child[c]]; base[c] = put(2 * c, g.x); put(2 * c + 1, g.y); }   // g.y's number is g.x's + 1
     }
-    float4* out = nodes + 8 * (size_t)i;
+    float org[3];
+    uint32_t eb[3], qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
     for (int a = 0; a < 3; ++a) {
-        out[a] = make_float4(lo[a][0], lo[a][1], lo[a][2], lo[a][3]);
-        out[3 + a] = make_float4(hi[a][0], hi[a][1], hi[a][2], hi[a][3]);
+        float o = __builtin_inff(), top = -__builtin_inff();
+        for (int s = 0; s < 4; ++s) if (kind[s]) { o = fminf(o, lo[s][a]); top = fmaxf(top, hi[s][a]); }
+        const float ext = top - o;
+        int e = -126;
+        if (ext > 0.0f) frexpf(ext * (1.0f / 254.0f), &e);   // ext / 254 = m 2^e, m in [0.5, 1): 254 steps of 2^e cover the extent
+        e = e < -126 ? -126 : (e > 126 ? 126 : e);
+        const float step = __int_as_float((e + 127) << 23), inv_step = __int_as_float((127 - e) << 23);
+        org[a] = o; eb[a] = (uint32_t)(e + 127);
+        for (int s = 0; s < 4; ++s) {
+            if (!kind[s]) continue;
+            int ql = (int)floorf((lo[s][a] - o) * inv_step), qh = (int)ceilf((hi[s][a] - o) * inv_step);
+            ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql); qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
+            while (ql > 0 && fmaf((float)ql, step, o) > lo[s][a]) --ql;     // the subtraction above was rounded
+            while (qh < 255 && fmaf((float)qh, step, o) < hi[s][a]) ++qh;
+            qlo[a] |= (uint32_t)ql << (8 * s); qhi[a] |= (uint32_t)qh << (8 * s);
+        }
     }
-    out[6] = make_float4(__int_as_float(link[0]), __int_as_float(link[1]), __int_as_float(link[2]), __int_as_float(link[3]));
-    out[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t kinds = (uint32_t)(kind[0] | kind[1] << 2 | kind[2] << 4 | kind[3] << 6);
+    const uint32_t meta = eb[0] | eb[1] << 8 | eb[2] << 16 | kinds << 24;
+    float4* out = nodes + 4 * (size_t)i;
+    out[0] = make_float4(org[0], org[1], org[2], __uint_as_float(meta));
+    out[1] = make_float4(__uint_as_float(qlo[0]), __uint_as_float(qhi[0]), __uint_as_float(qlo[1]), __uint_as_float(qhi[1]));
+    out[2] = make_float4(__uint_as_float(qlo[2]), __uint_as_float(qhi[2]), __int_as_float(base[0]), __int_as_float(base[1]));
+    out[3] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// Build the hierarchy over n_tris triangles (vertices in device order, 9 floats each) and n_spheres
-// spheres; *out_nodes receives n - 1 traversal nodes of 128 bytes (hipMalloc, owned by the caller).  Needs n >= 2.
-static hipError_t lbvh_build(hipStream_t st, const float* d_verts, int n_tris, const DevSphere* d_spheres, int n_spheres,
-                             float4** out_nodes) {
+// Leaf records in sorted order, 64 bytes each, so that a leaf's number is all a link has to carry:
+//   triangle  (n.xyz, -n.v0), (a.xyz, aw), (b.xyz, bw), (primitive, 0, -, index in the scene's object / face order)
+//   sphere    (centre, r^2), (is_light, -, -, -), -, (primitive, 1, -, 0x40000000 + sphere index)
+// primitive p < n_tris: triangle p in device order; otherwise sphere p - n_tris.  All integers as bit patterns.
+__global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_leaves(const int* __restrict__ vals, int n, int n_tris, const float4* __restrict__ tri_ab,
+                                                            const DevSphere* __restrict__ spheres, float4* __restrict__ leaves) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const int p = vals[g];
+    float4* out = leaves + 4 * (size_t)g;
+    if (p < n_tris) {
+        out[0] = tri_ab[4 * (size_t)p]; out[1] = tri_ab[4 * (size_t)p + 1]; out[2] = tri_ab[4 * (size_t)p + 2];
+        out[3] = make_float4(__int_as_float(p), __int_as_float(0), 0.f, tri_ab[4 * (size_t)p + 3].w);
+    } else {
+        const DevSphere sp = spheres[p - n_tris];
+        out[0] = make_float4(sp.cx, sp.cy, sp.cz, sp.r2);
+        out[1] = make_float4(__int_as_float(sp.is_light), 0.f, 0.f, 0.f);
+        out[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        out[3] = make_float4(__int_as_float(p), __int_as_float(1), 0.f, __int_as_float(0x40000000 + (p - n_tris)));
+    }
+}
+
+// Build the hierarchy over n_tris triangles (vertices in device order, 9 floats each; d_tri_ab their 64-byte
+// intersection records in the same order) and n_spheres spheres; *out_nodes receives n - 1 traversal nodes and
+// *out_leaves n leaf records of 64 bytes each (hipMalloc, owned by the caller).  Needs n >= 2.
+static hipError_t lbvh_build(hipStream_t st, const float* d_verts, const float4* d_tri_ab, int n_tris, const DevSphere* d_spheres,
+                             int n_spheres, float4** out_nodes, float4** out_leaves) {
     const int n = n_tris + n_spheres;
     LbvhWork w;
     hipError_t e = hipSuccess;
     float4* nodes = nullptr;
+    float4* leaves = nullptr;
     const int nt = n < 16384 * 16 ? (n + 15) / 16 : 16384;  // sort threads
     const int chunk = (n + nt - 1) / nt;
     auto blocks = [](int k) { return dim3((unsigned)((k + LBVH_BLOCK - 1) / LBVH_BLOCK)); };
-#define LB(x) do { e = (x); if (e != hipSuccess) { w.release(); hipFree(nodes); return e; } } while (0)
+#define LB(x) do { e = (x); if (e != hipSuccess) { w.release(); hipFree(nodes); hipFree(leaves); return e; } } while (0)
     LB(hipMalloc(&w.prim_lo, sizeof(float4) * n)); LB(hipMalloc(&w.prim_hi, sizeof(float4) * n));
     for (int k = 0; k < 2; ++k) { LB(hipMalloc(&w.keys[k], sizeof(uint32_t) * n)); LB(hipMalloc(&w.vals[k], sizeof(int) * n)); }
     LB(hipMalloc(&w.hist, sizeof(int) * 256 * (size_t)nt));
     LB(hipMalloc(&w.parent, sizeof(int) * (2 * (size_t)n - 1))); LB(hipMalloc(&w.kids, sizeof(int2) * (n - 1)));
     LB(hipMalloc(&w.box_lo, sizeof(float4) * (n - 1))); LB(hipMalloc(&w.box_hi, sizeof(float4) * (n - 1)));
     LB(hipMalloc(&w.flags, sizeof(int) * (n - 1))); LB(hipMalloc(&w.bounds, sizeof(int) * 6));
-    LB(hipMalloc(&nodes, sizeof(float4) * 8 * (size_t)(n - 1)));
+    LB(hipMalloc(&nodes, sizeof(float4) * 4 * (size_t)(n - 1)));
+    LB(hipMalloc(&leaves, sizeof(float4) * 4 * (size_t)n));
     const int init_bounds[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
     LB(hipMemcpyAsync(w.bounds, init_bounds, sizeof init_bounds, hipMemcpyHostToDevice, st));
     LB(hipStreamSynchronize(st));  // init_bounds is a stack array
@@ -301,10 +346,12 @@ static hipError_t lbvh_build(hipStream_t st, const float* d_verts, int n_tris, c
                        w.box_hi, w.flags);
     hipLaunchKernelGGL(k_lbvh_pack, blocks(n - 1), dim3(LBVH_BLOCK), 0, st, w.vals[cur], n, w.prim_lo, w.prim_hi, w.kids, w.box_lo, w.box_hi,
                        nodes);
+    hipLaunchKernelGGL(k_lbvh_leaves, blocks(n), dim3(LBVH_BLOCK), 0, st, w.vals[cur], n, n_tris, d_tri_ab, d_spheres, leaves);
     LB(hipGetLastError());
     LB(hipStreamSynchronize(st));
 #undef LB
     w.release();
     *out_nodes = nodes;
+    *out_leaves = leaves;
     return hipSuccess;
 }
