@@ -386,13 +386,18 @@ __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0
 }
 
 // ------------------------------------------------------------------------------------------------
-// closest hit through the LBVH (t3d_lbvh.h): one ray per lane, near child first, stack in private memory.
+// closest hit through the LBVH (t3d_lbvh.h): one ray per lane, near child first; the first T3D_BVH_LDS_STACK entries
+// of a lane's stack live in LDS, deeper ones (rare) in private memory.
 // Same acceptance rules as the brute-force loop; equal distances go to the primitive that comes first in
 // the scene's object / face order, whatever order the traversal meets them in.
 // ------------------------------------------------------------------------------------------------
 #ifndef T3D_BVH_STACK
 #define T3D_BVH_STACK 96
 #endif
+#ifndef T3D_BVH_LDS_STACK
+#define T3D_BVH_LDS_STACK 24   // entries per lane in LDS: 4 waves x 24 x 64 lanes x 4 B = 24 KB per block, 6 blocks per CU
+#endif
+#define T3D_BVH_DEEP_STACK (T3D_BVH_STACK - T3D_BVH_LDS_STACK)
 #ifndef T3D_BVH_WAVES
 #define T3D_BVH_WAVES 6   // waves per SIMD the traversal kernels are compiled for
 #endif
@@ -427,7 +432,9 @@ __device__ __forceinline__ void bvh_begin(BvhLane& s, V3 o, V3 d, bool lights, b
 
 // One step: a node record (four slab tests, entered slots pushed far to near, nearest descended into) or a leaf
 // (one triangle or sphere).  Returns true when nothing is left on the stack.
-__device__ __forceinline__ bool bvh_step(const DevScene& sc, BvhLane& s, int (&stack)[T3D_BVH_STACK], BvhCount& bc, int* stack_overflow) {
+// lds: this lane's column of the wave's LDS stack (entry e at lds[64 e]); deep: entries beyond it
+__device__ __forceinline__ bool bvh_step(const DevScene& sc, BvhLane& s, int* lds, int (&deep)[T3D_BVH_DEEP_STACK], BvhCount& bc,
+                                         int* stack_overflow) {
     const V3 o = s.o, d = s.d, inv = s.inv, oi = s.oi;
     if (s.node >= 0) {
         const float4* __restrict__ rec = sc.bvh.nodes + 4 * (size_t)s.node;
@@ -469,7 +476,9 @@ __device__ __forceinline__ bool bvh_step(const DevScene& sc, BvhLane& s, int (&s
 #pragma unroll
         for (int k = 3; k >= 1; --k) {
             if (tn[k] < __builtin_inff()) {
-                if (s.sp < T3D_BVH_STACK) { s.top = ln[k]; stack[s.sp++] = s.top; } else *stack_overflow = 1;
+                if (s.sp < T3D_BVH_LDS_STACK) { s.top = ln[k]; lds[64 * s.sp++] = s.top; }
+                else if (s.sp < T3D_BVH_STACK) { s.top = ln[k]; deep[s.sp++ - T3D_BVH_LDS_STACK] = s.top; }
+                else *stack_overflow = 1;
             }
         }
         if (tn[0] < __builtin_inff()) { s.node = ln[0]; return false; }
@@ -518,19 +527,22 @@ __device__ __forceinline__ bool bvh_step(const DevScene& sc, BvhLane& s, int (&s
     if (s.sp == 0) return true;
     s.node = s.top;
     --s.sp;
-    s.top = stack[s.sp > 0 ? s.sp - 1 : 0];
+    {
+        const int e = s.sp > 0 ? s.sp - 1 : 0;
+        s.top = e < T3D_BVH_LDS_STACK ? lds[64 * e] : deep[e - T3D_BVH_LDS_STACK];
+    }
     return false;
 }
 
 // Closest hit of one ray per lane; every lane runs until its own ray is finished.
 __device__ __forceinline__ void bvh_closest(const DevScene& sc, const DevSphere* __restrict__ spheres, V3 o, V3 d, bool active,
-                                            bool lights, bool back_cull, Hit& out, BvhCount& bc, int* stack_overflow) {
+                                            bool lights, bool back_cull, Hit& out, BvhCount& bc, int* stack_overflow, int* lds) {
     out.t = __builtin_inff(); out.prim = -1; out.back = 0;
     if (!active) return;
     BvhLane s;
-    int stack[T3D_BVH_STACK];
+    int deep[T3D_BVH_DEEP_STACK];
     bvh_begin(s, o, d, lights, back_cull);
-    while (!bvh_step(sc, s, stack, bc, stack_overflow)) {}
+    while (!bvh_step(sc, s, lds, deep, bc, stack_overflow)) {}
     out.t = s.best; out.prim = s.prim; out.back = s.back;
 }
 
@@ -984,8 +996,10 @@ __global__ __launch_bounds__(T3D_BLOCK, T3D_BVH_WAVES) void k_bvh_trace(DevScene
     const int queue_base = shard * shard_cap;
     const int w0 = LEVEL0 ? gw : gw / T3D_SHARDS, W = LEVEL0 ? nw : nw / T3D_SHARDS;
     const bool lights = LEVEL0 ? (rp.lights != 0) : true;
+    __shared__ int lds_stack[T3D_WAVES][T3D_BVH_LDS_STACK][64];
+    int* lds = &lds_stack[threadIdx.x >> 6][0][lane];
     BvhLane st;
-    int stack[T3D_BVH_STACK];
+    int deep[T3D_BVH_DEEP_STACK];
     BvhCount bc{0, 0, 0};
     bool have = false;     // a ray is in flight in this lane
     bool pending = false;  // a finished ray's result is still in st
@@ -1012,7 +1026,7 @@ __global__ __launch_bounds__(T3D_BLOCK, T3D_BVH_WAVES) void k_bvh_trace(DevScene
             }
             k += n_idle;
         }
-        if (have && bvh_step(sc, st, stack, bc, &cnt->bvh_stack_overflow)) { have = false; pending = true; }
+        if (have && bvh_step(sc, st, lds, deep, bc, &cnt->bvh_stack_overflow)) { have = false; pending = true; }
     }
     bvh_stats_flush(bc, cnt, lane, shard);
 }
@@ -1062,8 +1076,10 @@ __global__ __launch_bounds__(T3D_BLOCK, T3D_BVH_WAVES) void k_bvh_shadow(DevScen
     const long long n_in = (long long)min(cnt->n_nodes[level][shard].v, shard_cap) * L;  // (node, light) pairs of this shard
     const int w0 = gw / T3D_SHARDS, W = nw / T3D_SHARDS;
     const size_t node_base = (size_t)level * rp.cap;
+    __shared__ int lds_stack[T3D_WAVES][T3D_BVH_LDS_STACK][64];
+    int* lds = &lds_stack[threadIdx.x >> 6][0][lane];
     BvhLane st;
-    int stack[T3D_BVH_STACK];
+    int deep[T3D_BVH_DEEP_STACK];
     BvhCount bc{0, 0, 0};
     bool have = false, pending = false;
     int my_node = 0, my_light = 0;
@@ -1093,7 +1109,7 @@ __global__ __launch_bounds__(T3D_BLOCK, T3D_BVH_WAVES) void k_bvh_shadow(DevScen
             }
             k += n_idle;
         }
-        if (have && bvh_step(sc, st, stack, bc, &cnt->bvh_stack_overflow)) { have = false; pending = true; }
+        if (have && bvh_step(sc, st, lds, deep, bc, &cnt->bvh_stack_overflow)) { have = false; pending = true; }
     }
     bvh_stats_flush(bc, cnt, lane, shard);
 }
@@ -1175,9 +1191,10 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_closest(DevScene sc, GEO_PARAMS, 
     V3 d = normalize(mk(dirs[3 * j], dirs[3 * j + 1], dirs[3 * j + 2]));
     Hit h, h_dup;
     if (sc.bvh.nodes) {  // uniform over the launch
+        __shared__ int lds_stack[T3D_WAVES][T3D_BVH_LDS_STACK][64];
         BvhCount bc{0, 0, 0};
         int overflow = 0;
-        bvh_closest(sc, spheres, o, d, active, lights != 0, back_cull != 0, h, bc, &overflow);
+        bvh_closest(sc, spheres, o, d, active, lights != 0, back_cull != 0, h, bc, &overflow, &lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63]);
     } else {
         closest_hit2(GEO_ARGS, sc.geo, o, d, o, d, lights != 0, back_cull != 0, back_cull != 0, h, h_dup);
     }

@@ -20,11 +20,14 @@ if "--traffic-json" in sys.argv:
     import json
     out = sys.argv[sys.argv.index("--traffic-json") + 1]
     workload = sys.argv[sys.argv.index("--workload") + 1] if "--workload" in sys.argv else "cornell_1080p_b4"
-    f = [x for k, cs in acc.items() if k.startswith("k_level") for x in cs.get("FETCH_SIZE", [])]
-    w = [x for k, cs in acc.items() if k.startswith("k_level") for x in cs.get("WRITE_SIZE", [])]
-    if f and w:
-        fk, wk = sum(f) / len(f), sum(w) / len(w)
+    # one "launch" = the tracing of one tree level: a k_level launch, or k_bvh_trace + k_bvh_process + k_bvh_shadow
+    def level_sum(counter):
+        vals = [x for k, cs in acc.items() if k.startswith(("k_level", "k_bvh_")) for x in cs.get(counter, [])]
+        levels = sum(len(cs.get(counter, [])) for k, cs in acc.items() if k.startswith(("k_level", "k_bvh_trace")))
+        return (sum(vals) / levels, levels) if levels else (None, 0)
+    (fk, nf), (wk, nw) = level_sum("FETCH_SIZE"), level_sum("WRITE_SIZE")
+    if fk is not None and wk is not None:
         json.dump({"kernel": "k_level", "workload": workload, "fetch_size_kib_per_launch": round(fk, 1),
                    "write_size_kib_per_launch": round(wk, 1), "fetch_correction": 2.0,
-                   "hbm_bytes_per_launch": int((2.0 * fk + wk) * 1024), "launches_sampled": [len(f), len(w)]},
+                   "hbm_bytes_per_launch": int((2.0 * fk + wk) * 1024), "launches_sampled": [nf, nw]},
                   open(out, "w"), indent=1)
