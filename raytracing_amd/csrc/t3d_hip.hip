@@ -963,7 +963,7 @@ __global__ __launch_bounds__(T3D_BLOCK, 4) void k_level(DevScene sc, GEO_PARAMS,
 // T3D_REFILL_IDLE lanes are idle, so that the ray set-up is not run for one lane at a time.
 // ------------------------------------------------------------------------------------------------
 #ifndef T3D_REFILL_IDLE
-#define T3D_REFILL_IDLE 24
+#define T3D_REFILL_IDLE 16
 #endif
 
 // The wave's k-th ray (k counts the rays handed out so far) -> index in the level's list
