@@ -196,6 +196,7 @@ def main():
                                 "bytes_per_launch": nbytes / max(1, last["n_k_level"]),
                                 "nodes_visited_per_query": round(last["aabb_tests"] / 4 / max(1, last["queries"]), 2),
                                 "tri_tests_per_query": round(last["tri_tests"] / max(1, last["queries"]), 2),
+                                "deep_stack_pushes": last["bvh_deep_pushes"],
                                 "frame_device_ms": round(last["ms_device"], 4), "resolve_ms": round(last["ms_resolve"], 4)}
             if tr:
                 line["roofline"]["traffic"] = tr[0]["hbm_bytes_per_launch"]

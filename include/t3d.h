@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define T3D_ABI_VERSION 1
+#define T3D_ABI_VERSION 2
 
 enum {
     T3D_OK = 0,
@@ -110,6 +110,7 @@ typedef struct t3d_stats {
     uint64_t level_rays[T3D_STATS_MAX_LEVELS];   /* tree rays traced at the level                    */
     uint64_t level_nodes[T3D_STATS_MAX_LEVELS];  /* shaded nodes created at the level                */
     double level_ms[T3D_STATS_MAX_LEVELS];       /* duration of the level's k_level launch           */
+    uint64_t bvh_deep_pushes; /* LBVH path: traversal-stack entries that did not fit the per-lane LDS part   */
 } t3d_stats;
 
 /* One trace-tree node as t3d_trace_pixel returns it (TraceTreeNode, T3DE.py:273-280). */

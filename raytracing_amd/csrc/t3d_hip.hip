@@ -402,7 +402,7 @@ __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0
 #define T3D_BVH_WAVES 6   // waves per SIMD the traversal kernels are compiled for
 #endif
 struct BvhCount {
-    uint32_t nodes, tris, spheres;
+    uint32_t nodes, tris, spheres, deep;
 };
 
 // Traversal state of one ray (one lane).  bvh_begin sets it up, bvh_step advances it by one node record or one
@@ -477,7 +477,7 @@ __device__ __forceinline__ bool bvh_step(const DevScene& sc, BvhLane& s, int* ld
         for (int k = 3; k >= 1; --k) {
             if (tn[k] < __builtin_inff()) {
                 if (s.sp < T3D_BVH_LDS_STACK) { s.top = ln[k]; lds[64 * s.sp++] = s.top; }
-                else if (s.sp < T3D_BVH_STACK) { s.top = ln[k]; deep[s.sp++ - T3D_BVH_LDS_STACK] = s.top; }
+                else if (s.sp < T3D_BVH_STACK) { s.top = ln[k]; deep[s.sp++ - T3D_BVH_LDS_STACK] = s.top; bc.deep++; }
                 else *stack_overflow = 1;
             }
         }
@@ -971,14 +971,15 @@ __device__ __forceinline__ long long feed_index(int k, int w0, int W) { return (
 
 __device__ __forceinline__ void bvh_stats_flush(const BvhCount& bc, Counters* cnt, int lane, int shard) {
     // traversal statistics: wave sum, one atomic per counter on the wave's own counter line
-    unsigned long long a = bc.nodes, b = bc.tris, c = bc.spheres;
+    unsigned long long a = bc.nodes, b = bc.tris, c = bc.spheres, e = bc.deep;
     for (int off = 32; off > 0; off >>= 1) {
-        a += __shfl_xor(a, off); b += __shfl_xor(b, off); c += __shfl_xor(c, off);
+        a += __shfl_xor(a, off); b += __shfl_xor(b, off); c += __shfl_xor(c, off); e += __shfl_xor(e, off);
     }
     if (lane == 0) {
         atomicAdd(&cnt->bvh_stat[shard][0], a);
         atomicAdd(&cnt->bvh_stat[shard][1], b);
         atomicAdd(&cnt->bvh_stat[shard][2], c);
+        if (e) atomicAdd(&cnt->bvh_stat[shard][3], e);
     }
 }
 
@@ -1000,7 +1001,7 @@ __global__ __launch_bounds__(T3D_BLOCK, T3D_BVH_WAVES) void k_bvh_trace(DevScene
     int* lds = &lds_stack[threadIdx.x >> 6][0][lane];
     BvhLane st;
     int deep[T3D_BVH_DEEP_STACK];
-    BvhCount bc{0, 0, 0};
+    BvhCount bc{0, 0, 0, 0};
     bool have = false;     // a ray is in flight in this lane
     bool pending = false;  // a finished ray's result is still in st
     int mine = 0;          // where this lane's result goes
@@ -1080,7 +1081,7 @@ __global__ __launch_bounds__(T3D_BLOCK, T3D_BVH_WAVES) void k_bvh_shadow(DevScen
     int* lds = &lds_stack[threadIdx.x >> 6][0][lane];
     BvhLane st;
     int deep[T3D_BVH_DEEP_STACK];
-    BvhCount bc{0, 0, 0};
+    BvhCount bc{0, 0, 0, 0};
     bool have = false, pending = false;
     int my_node = 0, my_light = 0;
     int k = 0;
@@ -1192,7 +1193,7 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_closest(DevScene sc, GEO_PARAMS, 
     Hit h, h_dup;
     if (sc.bvh.nodes) {  // uniform over the launch
         __shared__ int lds_stack[T3D_WAVES][T3D_BVH_LDS_STACK][64];
-        BvhCount bc{0, 0, 0};
+        BvhCount bc{0, 0, 0, 0};
         int overflow = 0;
         bvh_closest(sc, spheres, o, d, active, lights != 0, back_cull != 0, h, bc, &overflow, &lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63]);
     } else {
@@ -1662,7 +1663,10 @@ static void fill_stats(t3d_ctx* c, t3d_stats* stats) {
     stats->shadow_queries += shadow;
     if (c->use_bvh) {
         uint64_t nv = 0, tt = 0, stt = 0;
-        for (int sh = 0; sh < T3D_SHARDS; ++sh) { nv += c->h_cnt->bvh_stat[sh][0]; tt += c->h_cnt->bvh_stat[sh][1]; stt += c->h_cnt->bvh_stat[sh][2]; }
+        for (int sh = 0; sh < T3D_SHARDS; ++sh) {
+            nv += c->h_cnt->bvh_stat[sh][0]; tt += c->h_cnt->bvh_stat[sh][1]; stt += c->h_cnt->bvh_stat[sh][2];
+            stats->bvh_deep_pushes += c->h_cnt->bvh_stat[sh][3];
+        }
         stats->aabb_tests += 4 * nv;  // every record visited holds four boxes
         stats->tri_tests += tt;
         stats->sphere_tests += stt;
@@ -1834,6 +1838,7 @@ extern "C" int t3d_render_rows_device(t3d_ctx* c, const t3d_opts* o, int row0, i
                     stats->level_rays[k] += band_stats.level_rays[k]; stats->level_nodes[k] += band_stats.level_nodes[k];
                     stats->level_ms[k] += band_stats.level_ms[k];
                 }
+                stats->bvh_deep_pushes += band_stats.bvh_deep_pushes;
             }
             break;
         }

@@ -54,7 +54,8 @@ class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays_api", "queries", "trace_queries", "shadow_queries", "tri_tests",
                                           "sphere_tests", "aabb_tests", "nodes", "launches", "n_k_level")] + \
                [(n, C.c_double) for n in ("ms_device", "ms_k_level", "ms_resolve")] + \
-               [("level_rays", C.c_uint64 * 16), ("level_nodes", C.c_uint64 * 16), ("level_ms", C.c_double * 16)]
+               [("level_rays", C.c_uint64 * 16), ("level_nodes", C.c_uint64 * 16), ("level_ms", C.c_double * 16),
+                ("bvh_deep_pushes", C.c_uint64)]
 
     def as_dict(self):
         return {name: (list(getattr(self, name)) if name.startswith("level_") else getattr(self, name))

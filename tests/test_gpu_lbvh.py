@@ -165,3 +165,34 @@ def test_cornell2_8k_full_size(gpu_ctx, oracle_mod):
     gpu_ctx.set_accel("auto")
     gpu_ctx.upload(flat)
     _frame_properties(gpu_ctx, oracle_mod, flat, opt, row_step=432)
+
+
+def test_deep_traversal_stack(gpu_ctx, oracle_mod):
+    """200 000 parallel sheets, every one of them in the way of every camera ray: on its first descent a ray
+    postpones three siblings per level of the hierarchy, more than the part of the stack that lives in LDS, so the
+    entries kept in private memory are used (and counted)."""
+    from dataclasses import replace
+    from raytracing_amd.workloads import synthetic_flat
+    n = 200_000
+    base = synthetic_flat(n_random_tris=4, grid=1, n_spheres=2, seed=1, extent=12.0, camera=(0.3713, 0.2117, -28.8))
+    z = np.linspace(-10.0, 10.0, n)
+    tri = np.empty((n, 3, 3))
+    tri[:, 0] = np.stack([np.full(n, -30.0), np.full(n, -30.0), z], 1)
+    tri[:, 1] = np.stack([np.zeros(n), np.full(n, 40.0), z], 1)          # wound to face the camera (normal along -z)
+    tri[:, 2] = np.stack([np.full(n, 30.0), np.full(n, -30.0), z], 1)
+    count = base.obj_tri_count.copy()
+    count[0] = n
+    flat = replace(base, tri_verts=np.ascontiguousarray(tri), tri_shader=np.full(n, 3, np.int32), obj_tri_count=count)
+    gpu_ctx.set_accel("auto")
+    gpu_ctx.upload(flat)
+    opt = dict(width=48, height=27, bounces=2, samples=1)
+    out = gpu_ctx.render_rows(opt, seed=5, want_radiance=True, want_primary=True)
+    assert out["stats"]["bvh_deep_pushes"] > 0
+    face = out["prim"][..., 1]
+    assert ((face == 0) | (face == -1)).all() and (face == 0).mean() > 0.5     # the first sheet or nothing
+    ref = oracle_mod.render(flat, opt, seed=5)
+    frag = oracle_mod.primary_fragility(flat, opt)
+    check_against_oracle(out, ref, frag)
+    # single-ray entry point through the same stack
+    hit = gpu_ctx.closest_hits([[0.1, 0.2, -28.8]], [[0.0, 0.0, 1.0]], True, True)
+    assert hit["face"][0] == 0 and abs(hit["t"][0] - 18.8) < 1e-4

@@ -12,6 +12,6 @@ for w in suzanne_4k_b4 synthetic_200k_1080p_b2 synthetic_1m_4k_b2; do
 import json
 d=json.load(open("gpurun_out/lbvh_${tag}_$w.json"))
 r=d["roofline"]
-print("$w", "ms/frame", d["ms_per_step"], "Mrays/s", d["value"], "nodes/query", r.get("nodes_visited_per_query"), "GB/s", r["achieved"])
+print("$w", "ms/frame", d["ms_per_step"], "Mrays/s", d["value"], "nodes/query", r.get("nodes_visited_per_query"), "GB/s", r["achieved"], "deep pushes", r.get("deep_stack_pushes"))
 PY
 done
