@@ -459,10 +459,10 @@ __device__ __forceinline__ bool bvh_step(const DevScene& sc, BvhLane& s, int* ld
             const float az = fmaf((float)((qlz >> (8 * k)) & 255u), sz, cz), bz = fmaf((float)((qhz >> (8 * k)) & 255u), sz, cz);
             const float near = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
             const float far = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), s.best)) * 1.0000004f;
-            const uint32_t kind = (meta >> (24 + 2 * k)) & 3u;
-            tn[k] = (near <= far && kind != 0u) ? near : __builtin_inff();   // +inf: not entered
-            const int number = (k < 2 ? base01 : base23) + (k & 1);
-            ln[k] = kind == 2u ? ~number : number;                           // leaves travel as negative links
+            const bool present = (meta & (1u << (24 + k))) != 0u;
+            tn[k] = (near <= far && present) ? near : __builtin_inff();   // +inf: not entered
+            const int leaf = ((int)(meta << (3 - k))) >> 31;                 // bit 28 + k, spread: -1 for a leaf, else 0
+            ln[k] = ((k < 2 ? base01 : base23) + (k & 1)) ^ leaf;            // leaves travel as negative links (~number)
         }
         // order the slots by entry distance (5 compare-exchanges), nearest first
         auto cswap = [&](int a, int b) {
@@ -472,13 +472,22 @@ __device__ __forceinline__ bool bvh_step(const DevScene& sc, BvhLane& s, int* ld
             tn[a] = ta; tn[b] = tb; ln[a] = la; ln[b] = lb;
         };
         cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2);
-        // push the entered slots 3, 2, 1 (farthest first), descend into slot 0
+        // push the entered slots 3, 2, 1 (farthest first), descend into slot 0.  Entered slots come first after the
+        // sort, so a slot that is not entered may be written all the same: the next push or a later one overwrites it.
+        const bool e1 = tn[1] < __builtin_inff(), e2 = tn[2] < __builtin_inff(), e3 = tn[3] < __builtin_inff();
+        if (s.sp + 3 <= T3D_BVH_LDS_STACK) {
+            lds[64 * s.sp] = ln[3]; s.sp += e3;
+            lds[64 * s.sp] = ln[2]; s.sp += e2;
+            lds[64 * s.sp] = ln[1]; s.sp += e1;
+            s.top = e1 ? ln[1] : s.top;
+        } else {
 #pragma unroll
-        for (int k = 3; k >= 1; --k) {
-            if (tn[k] < __builtin_inff()) {
-                if (s.sp < T3D_BVH_LDS_STACK) { s.top = ln[k]; lds[64 * s.sp++] = s.top; }
-                else if (s.sp < T3D_BVH_STACK) { s.top = ln[k]; deep[s.sp++ - T3D_BVH_LDS_STACK] = s.top; bc.deep++; }
-                else *stack_overflow = 1;
+            for (int k = 3; k >= 1; --k) {
+                if (tn[k] < __builtin_inff()) {
+                    if (s.sp < T3D_BVH_LDS_STACK) { s.top = ln[k]; lds[64 * s.sp++] = s.top; }
+                    else if (s.sp < T3D_BVH_STACK) { s.top = ln[k]; deep[s.sp++ - T3D_BVH_LDS_STACK] = s.top; bc.deep++; }
+                    else *stack_overflow = 1;
+                }
             }
         }
         if (tn[0] < __builtin_inff()) { s.node = ln[0]; return false; }

@@ -218,9 +218,8 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_refit(const int* __restrict
 // a leaf takes one slot itself), so one fetch decides four subtrees and a ray makes half as many dependent fetches
 // on its way down.  The traversal is bound by the number of 16-byte accesses a lane makes, not by arithmetic, so a
 // record is three rows (48 bytes used of a 64-byte stride, never straddling a cache line):
-//   row 0  origin.x, origin.y, origin.z of the record's own frame; meta = ex | ey << 8 | ez << 16 | kinds << 24
-//          (e*: biased exponent of the power-of-two grid step of the axis; kinds: 2 bits per slot, 0 empty,
-//          1 internal node, 2 leaf)
+//   row 0  origin.x, origin.y, origin.z of the record's own frame; meta = ex | ey << 8 | ez << 16 | used << 24 | leaf << 28
+//          (e*: biased exponent of the power-of-two grid step of the axis; used, leaf: one bit per slot)
 //   row 1  lo.x, hi.x, lo.y, hi.y of the four slots, one byte per slot (slot k in bits 8k..8k+7)
 //   row 2  lo.z, hi.z the same way; base01, base23
 // A slot's box is origin + q * step, lo rounded down and hi rounded up, so it contains the exact (padded) box.
@@ -271,8 +270,9 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_pack(const int* __restrict_
             qlo[a] |= (uint32_t)ql << (8 * s); qhi[a] |= (uint32_t)qh << (8 * s);
         }
     }
-    const uint32_t kinds = (uint32_t)(kind[0] | kind[1] << 2 | kind[2] << 4 | kind[3] << 6);
-    const uint32_t meta = eb[0] | eb[1] << 8 | eb[2] << 16 | kinds << 24;
+    uint32_t used = 0, leaf = 0;
+    for (int s = 0; s < 4; ++s) { used |= (uint32_t)(kind[s] != 0) << s; leaf |= (uint32_t)(kind[s] == 2) << s; }
+    const uint32_t meta = eb[0] | eb[1] << 8 | eb[2] << 16 | used << 24 | leaf << 28;
     float4* out = nodes + 4 * (size_t)i;
     out[0] = make_float4(org[0], org[1], org[2], __uint_as_float(meta));
     out[1] = make_float4(__uint_as_float(qlo[0]), __uint_as_float(qhi[0]), __uint_as_float(qlo[1]), __uint_as_float(qhi[1]));
