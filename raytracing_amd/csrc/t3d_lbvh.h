@@ -19,6 +19,7 @@ struct LbvhWork {
     uint32_t* keys[2] = {nullptr, nullptr};
     int* vals[2] = {nullptr, nullptr};
     int* hist = nullptr;
+    int* sums = nullptr;         // [1024] tile totals of the scan
     int* parent = nullptr;       // [2N-1]: internal nodes 0..N-2, leaves N-1..2N-2 (sorted position + N-1)
     int2* kids = nullptr;        // [N-1]
     float4* box_lo = nullptr;    // [N-1] boxes of internal nodes
@@ -27,7 +28,7 @@ struct LbvhWork {
     int* bounds = nullptr;       // [6] scene bounds as order-preserving ints
     void release() {
         hipFree(prim_lo); hipFree(prim_hi); hipFree(keys[0]); hipFree(keys[1]); hipFree(vals[0]); hipFree(vals[1]);
-        hipFree(hist); hipFree(parent); hipFree(kids); hipFree(box_lo); hipFree(box_hi); hipFree(flags); hipFree(bounds);
+        hipFree(hist); hipFree(sums); hipFree(parent); hipFree(kids); hipFree(box_lo); hipFree(box_hi); hipFree(flags); hipFree(bounds);
         *this = LbvhWork();
     }
 };
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_morton(const float4* __rest
 }
 
 // Stable LSD radix sort, 8 bits per pass.  Thread t owns the contiguous chunk [t*chunk, (t+1)*chunk): it
-// counts its digits into hist[digit * nt + t], a scan over the digit-major table gives every (digit, thread)
+// counts its digits into hist[digit * nt + t], an exclusive scan over the digit-major table gives every (digit, thread)
 // its first output slot, and the thread scatters its chunk in order.  Not a fast sort; the build runs once
 // per scene.
 __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_rs_count(const uint32_t* __restrict__ keys, int n, int shift, int chunk, int nt,
@@ -119,23 +120,41 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_rs_count(const uint32_t* __
     const int b = t * chunk, e = min(n, b + chunk);
     for (int i = b; i < e; ++i) hist[((keys[i] >> shift) & 255u) * nt + t] += 1;
 }
-__global__ __launch_bounds__(1024) void k_lbvh_rs_scan(int* __restrict__ hist, int m) {
-    __shared__ int part[1024];
+// Exclusive scan of the table in three launches: every block scans one tile of 4096 entries (4 per thread) and
+// leaves its total in sums[]; one block scans the totals; every tile then adds its offset.  m <= 1024 tiles.
+#define LBVH_SCAN_TILE 4096
+__device__ __forceinline__ int lbvh_block_exclusive(int v, int* part) {   // exclusive prefix of v over the 1024 threads of a block
     const int t = threadIdx.x;
-    const int per = (m + 1023) / 1024;
-    const int b = t * per, e = min(m, b + per);
-    int s = 0;
-    for (int i = b; i < e; ++i) s += hist[i];
-    part[t] = s;
+    part[t] = v;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
-        int v = t >= off ? part[t - off] : 0;
+        const int u = t >= off ? part[t - off] : 0;
         __syncthreads();
-        part[t] += v;
+        part[t] += u;
         __syncthreads();
     }
-    int run = part[t] - s;  // exclusive prefix of this thread's range
-    for (int i = b; i < e; ++i) { int v = hist[i]; hist[i] = run; run += v; }
+    return part[t] - v;
+}
+__global__ __launch_bounds__(1024) void k_lbvh_scan_tiles(int* __restrict__ hist, int m, int* __restrict__ sums) {
+    __shared__ int part[1024];
+    const int base = blockIdx.x * LBVH_SCAN_TILE + threadIdx.x * 4;
+    int v[4];
+    for (int j = 0; j < 4; ++j) v[j] = base + j < m ? hist[base + j] : 0;
+    const int total = v[0] + v[1] + v[2] + v[3];
+    int run = lbvh_block_exclusive(total, part);
+    for (int j = 0; j < 4; ++j) { if (base + j < m) hist[base + j] = run; run += v[j]; }
+    if (threadIdx.x == 1023) sums[blockIdx.x] = run;   // the last thread's running sum is the tile's total
+}
+__global__ __launch_bounds__(1024) void k_lbvh_scan_sums(int* __restrict__ sums, int n_tiles) {
+    __shared__ int part[1024];
+    const int v = (int)threadIdx.x < n_tiles ? sums[threadIdx.x] : 0;
+    const int ex = lbvh_block_exclusive(v, part);
+    if ((int)threadIdx.x < n_tiles) sums[threadIdx.x] = ex;
+}
+__global__ __launch_bounds__(1024) void k_lbvh_scan_add(int* __restrict__ hist, int m, const int* __restrict__ sums) {
+    const int base = blockIdx.x * LBVH_SCAN_TILE + threadIdx.x * 4;
+    const int off = sums[blockIdx.x];
+    for (int j = 0; j < 4; ++j) if (base + j < m) hist[base + j] += off;
 }
 __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_rs_scatter(const uint32_t* __restrict__ keys, const int* __restrict__ vals, int n, int shift,
                                                                 int chunk, int nt, int* __restrict__ hist, uint32_t* __restrict__ keys_out,
@@ -319,6 +338,7 @@ static hipError_t lbvh_build(hipStream_t st, const float* d_verts, const float4*
     LB(hipMalloc(&w.prim_lo, sizeof(float4) * n)); LB(hipMalloc(&w.prim_hi, sizeof(float4) * n));
     for (int k = 0; k < 2; ++k) { LB(hipMalloc(&w.keys[k], sizeof(uint32_t) * n)); LB(hipMalloc(&w.vals[k], sizeof(int) * n)); }
     LB(hipMalloc(&w.hist, sizeof(int) * 256 * (size_t)nt));
+    LB(hipMalloc(&w.sums, sizeof(int) * 1024));
     LB(hipMalloc(&w.parent, sizeof(int) * (2 * (size_t)n - 1))); LB(hipMalloc(&w.kids, sizeof(int2) * (n - 1)));
     LB(hipMalloc(&w.box_lo, sizeof(float4) * (n - 1))); LB(hipMalloc(&w.box_hi, sizeof(float4) * (n - 1)));
     LB(hipMalloc(&w.flags, sizeof(int) * (n - 1))); LB(hipMalloc(&w.bounds, sizeof(int) * 6));
@@ -335,7 +355,10 @@ static hipError_t lbvh_build(hipStream_t st, const float* d_verts, const float4*
     for (int shift = 0; shift < 32; shift += 8) {
         LB(hipMemsetAsync(w.hist, 0, sizeof(int) * 256 * (size_t)nt, st));
         hipLaunchKernelGGL(k_lbvh_rs_count, blocks(nt), dim3(LBVH_BLOCK), 0, st, w.keys[cur], n, shift, chunk, nt, w.hist);
-        hipLaunchKernelGGL(k_lbvh_rs_scan, dim3(1), dim3(1024), 0, st, w.hist, 256 * nt);
+        const int m = 256 * nt, n_tiles = (m + LBVH_SCAN_TILE - 1) / LBVH_SCAN_TILE;   // nt <= 16384: at most 1024 tiles
+        hipLaunchKernelGGL(k_lbvh_scan_tiles, dim3((unsigned)n_tiles), dim3(1024), 0, st, w.hist, m, w.sums);
+        hipLaunchKernelGGL(k_lbvh_scan_sums, dim3(1), dim3(1024), 0, st, w.sums, n_tiles);
+        hipLaunchKernelGGL(k_lbvh_scan_add, dim3((unsigned)n_tiles), dim3(1024), 0, st, w.hist, m, w.sums);
         hipLaunchKernelGGL(k_lbvh_rs_scatter, blocks(nt), dim3(LBVH_BLOCK), 0, st, w.keys[cur], w.vals[cur], n, shift, chunk, nt, w.hist,
                            w.keys[cur ^ 1], w.vals[cur ^ 1]);
         cur ^= 1;
