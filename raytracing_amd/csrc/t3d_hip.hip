@@ -966,17 +966,32 @@ __global__ __launch_bounds__(T3D_BLOCK, 4) void k_level(DevScene sc, GEO_PARAMS,
 //                  inputs of every new node (hit point, normal, roughness) go to src_a / src_b
 //   k_bvh_shadow   closest hit of the shadow ray of every (node, light) pair -> li[node][light]
 // Rays of one wave need very different numbers of traversal steps, and a wave lasts as long as its slowest lane.
-// The two traversal kernels therefore never wait for a whole batch: every wave owns a fixed, interleaved share of
-// the level's rays (64-ray chunks w0, w0 + W, ...) and hands the next ray of that share to a lane as soon as
-// the lane's ray is finished.  Refills are collective (ballot + prefix count, no atomics) and happen once
-// T3D_REFILL_IDLE lanes are idle, so that the ray set-up is not run for one lane at a time.
+// The two traversal kernels therefore never wait for a whole batch: a wave takes 64-ray chunks of its shard's list
+// from a counter (one atomic per chunk), so waves that get cheap rays simply take more, and hands the next ray of
+// its chunk to a lane as soon as the lane's ray is finished.  Refills are collective (ballot + prefix count) and
+// happen once T3D_REFILL_IDLE lanes are idle, so that the ray set-up is not run for one lane at a time.
 // ------------------------------------------------------------------------------------------------
 #ifndef T3D_REFILL_IDLE
 #define T3D_REFILL_IDLE 16
 #endif
 
-// The wave's k-th ray (k counts the rays handed out so far) -> index in the level's list
-__device__ __forceinline__ long long feed_index(int k, int w0, int W) { return ((long long)(k >> 6) * W + w0) * 64 + (k & 63); }
+// The part of a list a wave hands out to its lanes (all wave-uniform).
+struct RayFeed {
+    long long pos = 0, end = 0;   // entries pos .. end - 1 of the current chunk are still to be handed out
+    bool exhausted = false;       // the list has no chunk left
+};
+// Takes the next chunk when the current one is used up.  Called by all 64 lanes.  Lists of level 0 are not sharded:
+// there shard s owns chunks s, s + 64, ... of the one list (INTERLEAVED).
+template <bool INTERLEAVED>
+__device__ __forceinline__ void feed_refresh(RayFeed& f, PaddedCount* counter, int lane, int shard, long long n_in) {
+    if (f.pos < f.end || f.exhausted) return;
+    int j = 0;
+    if (lane == 0) j = atomicAdd(&counter->v, 1);
+    j = __builtin_amdgcn_readfirstlane(j);
+    const long long base = (INTERLEAVED ? (long long)j * T3D_SHARDS + shard : (long long)j) * 64;
+    if (base >= n_in) f.exhausted = true;
+    else { f.pos = base; f.end = base + 64 < n_in ? base + 64 : n_in; }
+}
 
 __device__ __forceinline__ void bvh_stats_flush(const BvhCount& bc, Counters* cnt, int lane, int shard) {
     // traversal statistics: wave sum, one atomic per counter on the wave's own counter line
@@ -995,16 +1010,14 @@ __device__ __forceinline__ void bvh_stats_flush(const BvhCount& bc, Counters* cn
 template <bool LEVEL0>
 __global__ __launch_bounds__(T3D_BLOCK, T3D_BVH_WAVES) void k_bvh_trace(DevScene sc, const DevSphere* __restrict__ spheres, RenderParams rp,
                                                                          int level, const RayRec* __restrict__ rays_in,
-                                                                         uint2* __restrict__ hits, Counters* cnt) {
+                                                                         uint2* __restrict__ hits, Counters* cnt, PaddedCount* fetch) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int gw = blockIdx.x * T3D_WAVES + (threadIdx.x >> 6);
-    const int nw = gridDim.x * T3D_WAVES;  // multiple of T3D_SHARDS (host guarantees)
-    const int shard = gw % T3D_SHARDS;
+    const int shard = gw % T3D_SHARDS;   // the grid holds a multiple of T3D_SHARDS waves (host guarantees)
     const int shard_cap = rp.cap / T3D_SHARDS;
     const int n_in = LEVEL0 ? rp.n0 : min(cnt->n_rays[level][shard].v, shard_cap);
     const int queue_base = shard * shard_cap;
-    const int w0 = LEVEL0 ? gw : gw / T3D_SHARDS, W = LEVEL0 ? nw : nw / T3D_SHARDS;
     const bool lights = LEVEL0 ? (rp.lights != 0) : true;
     __shared__ int lds_stack[T3D_WAVES][T3D_BVH_LDS_STACK][64];
     int* lds = &lds_stack[threadIdx.x >> 6][0][lane];
@@ -1014,27 +1027,27 @@ __global__ __launch_bounds__(T3D_BLOCK, T3D_BVH_WAVES) void k_bvh_trace(DevScene
     bool have = false;     // a ray is in flight in this lane
     bool pending = false;  // a finished ray's result is still in st
     int mine = 0;          // where this lane's result goes
-    int k = 0;             // rays of this wave's share handed out so far (wave-uniform)
+    RayFeed feed;
     for (;;) {
         const int n_idle = __popcll(__ballot(!have));
-        const bool more = feed_index(k, w0, W) < n_in;
-        if ((more && n_idle >= T3D_REFILL_IDLE) || n_idle == 64) {
+        if ((!feed.exhausted && n_idle >= T3D_REFILL_IDLE) || n_idle == 64) {
             // service point, shared by all idle lanes: results out, next rays in
             const unsigned long long idle = __ballot(!have);
             if (pending) {
                 hits[mine] = make_uint2(__float_as_uint(st.best) | ((uint32_t)st.back << 31), (uint32_t)st.prim);
                 pending = false;
             }
-            if (!more) break;  // all 64 lanes idle and nothing left to hand out
-            const long long idx = feed_index(k + __popcll(idle & lt_mask), w0, W);
-            if (!have && idx < n_in) {
+            feed_refresh<LEVEL0>(feed, &fetch[shard], lane, shard, n_in);
+            if (feed.exhausted && n_idle == 64) break;  // nothing in flight and nothing left to hand out
+            const long long idx = feed.pos + __popcll(idle & lt_mask);
+            if (!have && idx < feed.end) {
                 RayIn in;
                 load_ray<LEVEL0>(sc, rp, rays_in, (int)idx, n_in, queue_base, in);
                 mine = in.i;
                 bvh_begin(st, in.o, in.d, lights, in.ior == 1.0f);  // back faces culled iff ray.ior == 1 (T3DR.py:961)
                 have = true;
             }
-            k += n_idle;
+            feed.pos = feed.pos + n_idle < feed.end ? feed.pos + n_idle : feed.end;
         }
         if (have && bvh_step(sc, st, lds, deep, bc, &cnt->bvh_stack_overflow)) { have = false; pending = true; }
     }
@@ -1075,16 +1088,15 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_bvh_process(DevScene sc, const De
 
 __global__ __launch_bounds__(T3D_BLOCK, T3D_BVH_WAVES) void k_bvh_shadow(DevScene sc, const DevSphere* __restrict__ spheres, RenderParams rp,
                                                                           int level, const float4* __restrict__ src_a,
-                                                                          const float4* __restrict__ src_b, NodePool pool, Counters* cnt) {
+                                                                          const float4* __restrict__ src_b, NodePool pool, Counters* cnt,
+                                                                          PaddedCount* fetch) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int gw = blockIdx.x * T3D_WAVES + (threadIdx.x >> 6);
-    const int nw = gridDim.x * T3D_WAVES;
     const int shard = gw % T3D_SHARDS;
     const int shard_cap = rp.cap / T3D_SHARDS;
     const int L = sc.n_lights;
     const long long n_in = (long long)min(cnt->n_nodes[level][shard].v, shard_cap) * L;  // (node, light) pairs of this shard
-    const int w0 = gw / T3D_SHARDS, W = nw / T3D_SHARDS;
     const size_t node_base = (size_t)level * rp.cap;
     __shared__ int lds_stack[T3D_WAVES][T3D_BVH_LDS_STACK][64];
     int* lds = &lds_stack[threadIdx.x >> 6][0][lane];
@@ -1093,11 +1105,10 @@ __global__ __launch_bounds__(T3D_BLOCK, T3D_BVH_WAVES) void k_bvh_shadow(DevScen
     BvhCount bc{0, 0, 0, 0};
     bool have = false, pending = false;
     int my_node = 0, my_light = 0;
-    int k = 0;
+    RayFeed feed;
     for (;;) {
         const int n_idle = __popcll(__ballot(!have));
-        const bool more = feed_index(k, w0, W) < n_in;
-        if ((more && n_idle >= T3D_REFILL_IDLE) || n_idle == 64) {
+        if ((!feed.exhausted && n_idle >= T3D_REFILL_IDLE) || n_idle == 64) {
             const unsigned long long idle = __ballot(!have);
             if (pending) {
                 // the shading inputs are read again rather than kept in registers across the traversal
@@ -1107,9 +1118,10 @@ __global__ __launch_bounds__(T3D_BLOCK, T3D_BVH_WAVES) void k_bvh_shadow(DevScen
                 pool.li[(node_base + (size_t)my_node) * L + my_light] = shadow_intensity(sc, spheres, s, h);
                 pending = false;
             }
-            if (!more) break;
-            const long long idx = feed_index(k + __popcll(idle & lt_mask), w0, W);
-            if (!have && idx < n_in) {
+            feed_refresh<false>(feed, &fetch[shard], lane, shard, n_in);
+            if (feed.exhausted && n_idle == 64) break;
+            const long long idx = feed.pos + __popcll(idle & lt_mask);
+            if (!have && idx < feed.end) {
                 const int nd = (int)(idx / L);
                 my_light = (int)(idx - (long long)nd * L);
                 my_node = shard * shard_cap + nd;
@@ -1117,7 +1129,7 @@ __global__ __launch_bounds__(T3D_BLOCK, T3D_BVH_WAVES) void k_bvh_shadow(DevScen
                 bvh_begin(st, s.start, s.Ld, true, false);
                 have = true;
             }
-            k += n_idle;
+            feed.pos = feed.pos + n_idle < feed.end ? feed.pos + n_idle : feed.end;
         }
         if (have && bvh_step(sc, st, lds, deep, bc, &cnt->bvh_stack_overflow)) { have = false; pending = true; }
     }
@@ -1258,6 +1270,7 @@ struct t3d_ctx {
     float4* d_sample_color = nullptr;
     Counters* d_cnt = nullptr;
     Counters* h_cnt = nullptr;  // pinned
+    PaddedCount* d_fetch = nullptr;  // LBVH path: chunk counters of the traversal kernels, [level][trace, shadow][shard]
     // staging for host outputs
     size_t out_alloc = 0;
     uint8_t* d_bgr = nullptr; float* d_rad = nullptr; int32_t* d_prim = nullptr; float* d_prim_t = nullptr;
@@ -1308,6 +1321,7 @@ extern "C" int t3d_create(int device, t3d_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_sm = prop.multiProcessorCount;
     if (hipMalloc((void**)&c->d_cnt, sizeof(Counters)) != hipSuccess ||
+        hipMalloc((void**)&c->d_fetch, sizeof(PaddedCount) * (T3D_MAX_BOUNCES + 2) * 2 * T3D_SHARDS) != hipSuccess ||
         hipHostMalloc((void**)&c->h_cnt, sizeof(Counters), hipHostMallocDefault) != hipSuccess) {
         g_create_err = "t3d_create: counter allocation failed";
         delete c;
@@ -1339,7 +1353,7 @@ extern "C" void t3d_destroy(t3d_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     free_scene(c); free_work(c);
-    hipFree(c->d_sample_color); hipFree(c->d_cnt); hipHostFree(c->h_cnt);
+    hipFree(c->d_sample_color); hipFree(c->d_cnt); hipFree(c->d_fetch); hipHostFree(c->h_cnt);
     hipFree(c->d_bgr); hipFree(c->d_rad); hipFree(c->d_prim); hipFree(c->d_prim_t);
     for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -1718,6 +1732,7 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
     }
 
     HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), st));
+    if (c->use_bvh) HIPCHK(c, hipMemsetAsync(c->d_fetch, 0, sizeof(PaddedCount) * (size_t)levels * 2 * T3D_SHARDS, st));
     TraceOut out{c->d_sample_color, d_prim, d_prim_t, d_dbg, dbg_cap};
     const int max_blocks = c->n_sm * 8;
     auto blocks_for = [&](size_t n) { size_t b = (n + T3D_BLOCK - 1) / T3D_BLOCK; return (int)(b < 1 ? 1 : (b > (size_t)max_blocks ? (size_t)max_blocks : b)); };
@@ -1751,12 +1766,13 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
         const int grid_n = single ? (int)grid_unit : trace_blocks_for(d == 0 ? n0 : c->cap_alloc);
         if (c->use_bvh) {
             const int grid_r = single ? (int)grid_unit : resident_blocks_for(d == 0 ? n0 : c->cap_alloc);
+            PaddedCount* fetch_t = c->d_fetch + (size_t)d * 2 * T3D_SHARDS;
             if (d == 0) {
-                hipLaunchKernelGGL(k_bvh_trace<true>, dim3(grid_r), dim3(T3D_BLOCK), 0, st, c->sc, sph, rp, d, in, c->d_hits, c->d_cnt);
+                hipLaunchKernelGGL(k_bvh_trace<true>, dim3(grid_r), dim3(T3D_BLOCK), 0, st, c->sc, sph, rp, d, in, c->d_hits, c->d_cnt, fetch_t);
                 hipLaunchKernelGGL(k_bvh_process<true>, dim3(grid_n), dim3(T3D_BLOCK), 0, st, c->sc, sph, rp, d, in, outq, c->d_hits, c->pool,
                                    c->d_cnt, out, c->d_src_a, c->d_src_b);
             } else {
-                hipLaunchKernelGGL(k_bvh_trace<false>, dim3(grid_r), dim3(T3D_BLOCK), 0, st, c->sc, sph, rp, d, in, c->d_hits, c->d_cnt);
+                hipLaunchKernelGGL(k_bvh_trace<false>, dim3(grid_r), dim3(T3D_BLOCK), 0, st, c->sc, sph, rp, d, in, c->d_hits, c->d_cnt, fetch_t);
                 hipLaunchKernelGGL(k_bvh_process<false>, dim3(grid_n), dim3(T3D_BLOCK), 0, st, c->sc, sph, rp, d, in, outq, c->d_hits, c->pool,
                                    c->d_cnt, out, c->d_src_a, c->d_src_b);
             }
@@ -1764,7 +1780,7 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
             if (c->sc.n_lights > 0) {
                 const size_t pairs = (d == 0 ? n0 : c->cap_alloc) * (size_t)c->sc.n_lights;
                 hipLaunchKernelGGL(k_bvh_shadow, dim3(single ? (int)grid_unit : resident_blocks_for(pairs)), dim3(T3D_BLOCK), 0, st, c->sc, sph, rp,
-                                   d, c->d_src_a, c->d_src_b, c->pool, c->d_cnt);
+                                   d, c->d_src_a, c->d_src_b, c->pool, c->d_cnt, fetch_t + T3D_SHARDS);
                 launches += 1;
             }
         } else {

@@ -1,17 +1,21 @@
 """What one rank of an N-GPU run does per frame, timed on one GPU: rows r, r+N, ... of the benchmark frame
-(no gather).  Shows the fixed per-frame cost that limits strong scaling."""
+(no gather); usage: rank_emulation.py [workload] [N ...].  Shows the fixed per-frame cost that limits strong scaling."""
 import sys, time
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from raytracing_amd import _native
 from raytracing_amd.workloads import get_flat_workload
-flat, opt = get_flat_workload("cornell_1080p_b4")
+args = sys.argv[1:]
+workload = "cornell_1080p_b4"
+if args and not args[0].isdigit():
+    workload = args.pop(0)
+flat, opt = get_flat_workload(workload)
 ctx = _native.Context(0); ctx.upload(flat)
 H, W = opt["height"], opt["width"]
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream(dev).cuda_stream
-for n in ([int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]):
+for n in ([int(a) for a in args] or [1, 2, 4, 8]):
     rows = H // n
     out = torch.empty((rows, W, 3), dtype=torch.uint8, device=dev)
     st = ctx.render_rows_device(opt, 0, 0, rows, out.data_ptr(), stream=stream, want_stats=True, row_stride=n)
@@ -20,7 +24,7 @@ for n in ([int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]):
         ctx.render_rows_device(opt, 0, 0, rows, out.data_ptr(), stream=stream, want_stats=False, row_stride=n)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    K = 50
+    K = 50 if workload == "cornell_1080p_b4" else 5
     for _ in range(K):
         ctx.render_rows_device(opt, 0, 0, rows, out.data_ptr(), stream=stream, want_stats=False, row_stride=n)
     torch.cuda.synchronize()
