@@ -1265,7 +1265,11 @@ struct t3d_ctx {
     RayRec* d_rays[2] = {nullptr, nullptr};
     NodePool pool{};
     // LBVH path only: closest hit of every ray of the current level; shading inputs of its new nodes
-    uint2* d_hits = nullptr; float4* d_src_a = nullptr; float4* d_src_b = nullptr;
+    uint2* d_hits = nullptr;
+    float4* d_src_a[2] = {nullptr, nullptr}; float4* d_src_b[2] = {nullptr, nullptr};  // by level parity: see render_band
+    hipStream_t shadow_stream = nullptr;             // k_bvh_shadow of level d runs beside the tracing of level d + 1
+    hipEvent_t ev_traced[T3D_MAX_BOUNCES + 2] = {};  // level d classified: its shadow rays may start
+    hipEvent_t ev_shadowed[T3D_MAX_BOUNCES + 2] = {};  // shadow rays of level d done
     size_t n0_alloc = 0;
     float4* d_sample_color = nullptr;
     Counters* d_cnt = nullptr;
@@ -1318,6 +1322,9 @@ extern "C" int t3d_create(int device, t3d_ctx** out) {
         return T3D_E_DEVICE;
     }
     for (auto& ev : c->ev) hipEventCreate(&ev);
+    for (auto& ev : c->ev_traced) hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    for (auto& ev : c->ev_shadowed) hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    hipStreamCreateWithFlags(&c->shadow_stream, hipStreamNonBlocking);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_sm = prop.multiProcessorCount;
     if (hipMalloc((void**)&c->d_cnt, sizeof(Counters)) != hipSuccess ||
@@ -1343,8 +1350,9 @@ static void free_scene(t3d_ctx* c) {
 static void free_work(t3d_ctx* c) {
     hipFree(c->d_rays[0]); hipFree(c->d_rays[1]); hipFree(c->pool.parent); hipFree(c->pool.c);
     hipFree(c->pool.d); hipFree(c->pool.dbg); hipFree(c->pool.li);
-    hipFree(c->d_hits); hipFree(c->d_src_a); hipFree(c->d_src_b);
-    c->d_hits = nullptr; c->d_src_a = c->d_src_b = nullptr;
+    hipFree(c->d_hits);
+    c->d_hits = nullptr;
+    for (int k = 0; k < 2; ++k) { hipFree(c->d_src_a[k]); hipFree(c->d_src_b[k]); c->d_src_a[k] = c->d_src_b[k] = nullptr; }
     c->d_rays[0] = c->d_rays[1] = nullptr; c->pool = NodePool{}; c->cap_alloc = 0; c->levels_alloc = 0;
 }
 
@@ -1356,6 +1364,9 @@ extern "C" void t3d_destroy(t3d_ctx* c) {
     hipFree(c->d_sample_color); hipFree(c->d_cnt); hipFree(c->d_fetch); hipHostFree(c->h_cnt);
     hipFree(c->d_bgr); hipFree(c->d_rad); hipFree(c->d_prim); hipFree(c->d_prim_t);
     for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
+    for (auto& ev : c->ev_traced) if (ev) hipEventDestroy(ev);
+    for (auto& ev : c->ev_shadowed) if (ev) hipEventDestroy(ev);
+    if (c->shadow_stream) { hipStreamSynchronize(c->shadow_stream); hipStreamDestroy(c->shadow_stream); }
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1623,8 +1634,10 @@ static int ensure_work(t3d_ctx* c, size_t cap, int levels, size_t n0, bool dbg) 
         if (dbg) HIPCHK(c, hipMalloc((void**)&c->pool.dbg, sizeof(int) * cap2 * lv));
         if (c->use_bvh) {
             HIPCHK(c, hipMalloc((void**)&c->d_hits, sizeof(uint2) * cap2));
-            HIPCHK(c, hipMalloc((void**)&c->d_src_a, sizeof(float4) * cap2));
-            HIPCHK(c, hipMalloc((void**)&c->d_src_b, sizeof(float4) * cap2));
+            for (int k = 0; k < 2; ++k) {
+                HIPCHK(c, hipMalloc((void**)&c->d_src_a[k], sizeof(float4) * cap2));
+                HIPCHK(c, hipMalloc((void**)&c->d_src_b[k], sizeof(float4) * cap2));
+            }
         }
         HIPCHK(c, hipMalloc((void**)&c->pool.li, sizeof(float) * cap2 * lv * (size_t)(c->sc.n_lights > 0 ? c->sc.n_lights : 1)));
         c->li_lights = c->sc.n_lights;
@@ -1759,6 +1772,8 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
         b = (b + grid_unit - 1) / grid_unit * grid_unit;
         return (int)b;
     };
+    // per-level timing wants the levels one after the other
+    const bool overlap = c->use_bvh && !c->timing && !single;
     HIPCHK(c, tick());  // ev[0]: start of the call
     for (int d = 0; d < levels; ++d) {
         RayRec* in = c->d_rays[d & 1];
@@ -1767,20 +1782,32 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
         if (c->use_bvh) {
             const int grid_r = single ? (int)grid_unit : resident_blocks_for(d == 0 ? n0 : c->cap_alloc);
             PaddedCount* fetch_t = c->d_fetch + (size_t)d * 2 * T3D_SHARDS;
+            float4* src_a = c->d_src_a[d & 1];
+            float4* src_b = c->d_src_b[d & 1];
+            // the classification of level d overwrites the shading inputs that the shadow rays of level d - 2 read
+            if (overlap && d >= 2 && c->sc.n_lights > 0) HIPCHK(c, hipStreamWaitEvent(st, c->ev_shadowed[d - 2], 0));
             if (d == 0) {
                 hipLaunchKernelGGL(k_bvh_trace<true>, dim3(grid_r), dim3(T3D_BLOCK), 0, st, c->sc, sph, rp, d, in, c->d_hits, c->d_cnt, fetch_t);
                 hipLaunchKernelGGL(k_bvh_process<true>, dim3(grid_n), dim3(T3D_BLOCK), 0, st, c->sc, sph, rp, d, in, outq, c->d_hits, c->pool,
-                                   c->d_cnt, out, c->d_src_a, c->d_src_b);
+                                   c->d_cnt, out, src_a, src_b);
             } else {
                 hipLaunchKernelGGL(k_bvh_trace<false>, dim3(grid_r), dim3(T3D_BLOCK), 0, st, c->sc, sph, rp, d, in, c->d_hits, c->d_cnt, fetch_t);
                 hipLaunchKernelGGL(k_bvh_process<false>, dim3(grid_n), dim3(T3D_BLOCK), 0, st, c->sc, sph, rp, d, in, outq, c->d_hits, c->pool,
-                                   c->d_cnt, out, c->d_src_a, c->d_src_b);
+                                   c->d_cnt, out, src_a, src_b);
             }
             launches += 2;
             if (c->sc.n_lights > 0) {
+                // The shadow rays of level d need its classification only, and the rays of level d + 1 do not need
+                // them: on a stream of their own they fill the device while the next level's kernels drain and start.
+                hipStream_t ss = overlap ? c->shadow_stream : st;
+                if (overlap) {
+                    HIPCHK(c, hipEventRecord(c->ev_traced[d], st));
+                    HIPCHK(c, hipStreamWaitEvent(ss, c->ev_traced[d], 0));
+                }
                 const size_t pairs = (d == 0 ? n0 : c->cap_alloc) * (size_t)c->sc.n_lights;
-                hipLaunchKernelGGL(k_bvh_shadow, dim3(single ? (int)grid_unit : resident_blocks_for(pairs)), dim3(T3D_BLOCK), 0, st, c->sc, sph, rp,
-                                   d, c->d_src_a, c->d_src_b, c->pool, c->d_cnt, fetch_t + T3D_SHARDS);
+                hipLaunchKernelGGL(k_bvh_shadow, dim3(single ? (int)grid_unit : resident_blocks_for(pairs)), dim3(T3D_BLOCK), 0, ss, c->sc, sph, rp,
+                                   d, src_a, src_b, c->pool, c->d_cnt, fetch_t + T3D_SHARDS);
+                if (overlap) HIPCHK(c, hipEventRecord(c->ev_shadowed[d], ss));
                 launches += 1;
             }
         } else {
@@ -1794,6 +1821,8 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
         }
         if (c->timing) HIPCHK(c, tick());  // ev[1 + d]: level d traced
     }
+    if (overlap && c->sc.n_lights > 0)   // the resolve reads every level's light intensities
+        for (int d = levels >= 2 ? levels - 2 : 0; d < levels; ++d) HIPCHK(c, hipStreamWaitEvent(st, c->ev_shadowed[d], 0));
     for (int d = levels - 1; d >= 0; --d) {
         hipLaunchKernelGGL(k_resolve, dim3(single ? (int)grid_unit : trace_blocks_for(c->cap_alloc)), dim3(T3D_BLOCK), 0, st, c->sc, rp, d, c->pool, c->d_cnt,
                            c->d_sample_color, d_dbg, dbg_cap);
@@ -1829,7 +1858,7 @@ extern "C" int t3d_render_rows_device(t3d_ctx* c, const t3d_opts* o, int row0, i
     const int S = o->bounces > 1 ? o->samples : 1;
     const int levels = o->bounces + 1;
     // rows per band: the optimistic working set (capacity factor 2 per level) must fit the budget
-    const size_t per_sample = (size_t)2 * (2 * sizeof(RayRec) + (c->use_bvh ? sizeof(uint2) + 2 * sizeof(float4) : 0) +
+    const size_t per_sample = (size_t)2 * (2 * sizeof(RayRec) + (c->use_bvh ? sizeof(uint2) + 4 * sizeof(float4) : 0) +
                                            (size_t)levels * (36 + 4 * (size_t)(c->sc.n_lights > 0 ? c->sc.n_lights : 1))) + sizeof(float4);
     size_t max_samples = c->mem_budget / per_sample;
     size_t max_idx = (size_t)0x7FFFFFF0 / ((size_t)levels * 2);
