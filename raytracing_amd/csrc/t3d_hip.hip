@@ -12,6 +12,9 @@
 //                 popcount, one atomic per counter per round, counters sharded 64 ways);
 //                 shadow round: 128 (node, light) pairs from an LDS ring of the wave's shaded nodes --
 //                 shadow-ray closest hit, direct-light intensity (T3DR.py:820-900)
+//                 Scenes traced through the LBVH (t3d_lbvh.h) run a level as three launches instead:
+//                 k_bvh_trace (closest hits), k_bvh_process (the same classification), k_bvh_shadow;
+//                 see the comment above k_bvh_trace.
 //   for depth d = bounces .. 0:
 //       k_resolve one thread per node: computeColor (T3DR.py:1004-1083) from the two child slots
 //                 and the direct light, pushes the colour into the parent's slot
