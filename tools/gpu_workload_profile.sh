@@ -11,3 +11,4 @@ rc=$?
 cd $R
 if [ $rc -ne 0 ]; then echo "BENCH FAILED rc=$rc"; tail -20 gpurun_out/prof_$tag.err; exit $rc; fi
 python tools/prof_summary.py gpurun_out/prof_$tag/*/*_kernel_trace.csv
+python tools/prof_summary.py gpurun_out/prof_$tag/*/*_kernel_trace.csv --frame 1 | sed -n '/frame launch/,$p'

@@ -14,10 +14,13 @@ for r in rows:
 print(f"{'kernel':28s} {'calls':>6s} {'total_us':>10s} {'avg_us':>9s} vgpr sgpr lds scratch")
 for k, t in sorted(tot.items(), key=lambda kv: -kv[1][1]):
     print(f"{k:28s} {t[0]:6d} {t[1]/1e3:10.1f} {t[1]/t[0]/1e3:9.2f} {t[2]:>4s} {t[3]:>4s} {t[4]:>3s} {t[5]:>3s}")
-# last frame = launches after the last k_trace<true>
-idx = max(i for i, r in enumerate(rows) if short(r["Kernel_Name"]).startswith(("k_trace<true", "k_level<true", "k_bvh_trace<true")))
+# a frame = the launches from a level-0 kernel on; the last one by default (bench.py times its levels one after the
+# other there), --frame K for the K-th from the end (1 = the one before the last: untimed, kernels may overlap)
+back = int(sys.argv[sys.argv.index("--frame") + 1]) if "--frame" in sys.argv else 0
+starts = [i for i, r in enumerate(rows) if short(r["Kernel_Name"]).startswith(("k_trace<true", "k_level<true", "k_bvh_trace<true"))]
+idx = starts[-1 - back]
 t0 = int(rows[idx]["Start_Timestamp"])
-print("\nlast frame launch sequence (start offset us, duration us, grid):")
+print("\nframe launch sequence (start offset us, duration us, grid):")
 for r in rows[idx:]:
     k = short(r["Kernel_Name"])
     print(f"  {(int(r['Start_Timestamp'])-t0)/1e3:9.1f} {(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3:9.1f}  {k:24s} {r['Grid_Size_X']}")
