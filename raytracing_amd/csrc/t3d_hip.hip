@@ -1280,6 +1280,7 @@ struct t3d_ctx {
     PaddedCount* d_fetch = nullptr;  // LBVH path: chunk counters of the traversal kernels, [level][trace, shadow][shard]
     // staging for host outputs
     size_t out_alloc = 0;
+    void* h_stage = nullptr; size_t stage_alloc = 0;  // pinned: device -> pinned -> caller's (pageable) buffers
     uint8_t* d_bgr = nullptr; float* d_rad = nullptr; int32_t* d_prim = nullptr; float* d_prim_t = nullptr;
     size_t mem_budget = (size_t)48 << 30;
     // the most recent band, for t3d_last_call_stats
@@ -1366,6 +1367,7 @@ extern "C" void t3d_destroy(t3d_ctx* c) {
     free_scene(c); free_work(c);
     hipFree(c->d_sample_color); hipFree(c->d_cnt); hipFree(c->d_fetch); hipHostFree(c->h_cnt);
     hipFree(c->d_bgr); hipFree(c->d_rad); hipFree(c->d_prim); hipFree(c->d_prim_t);
+    if (c->h_stage) hipHostFree(c->h_stage);
     for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
     for (auto& ev : c->ev_traced) if (ev) hipEventDestroy(ev);
     for (auto& ev : c->ev_shadowed) if (ev) hipEventDestroy(ev);
@@ -1948,11 +1950,28 @@ extern "C" int t3d_render_rows(t3d_ctx* c, const t3d_opts* o, int row0, int nrow
     rc = t3d_render_rows_device(c, o, row0, nrows, c->d_bgr, radiance_out ? c->d_rad : nullptr, primary_out ? c->d_prim : nullptr,
                                 primary_t_out ? c->d_prim_t : nullptr, nullptr, &local);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(bgr_out, c->d_bgr, npix * 3, hipMemcpyDeviceToHost, c->stream));
-    if (radiance_out) HIPCHK(c, hipMemcpyAsync(radiance_out, c->d_rad, npix * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    if (primary_out) HIPCHK(c, hipMemcpyAsync(primary_out, c->d_prim, npix * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    if (primary_t_out) HIPCHK(c, hipMemcpyAsync(primary_t_out, c->d_prim_t, npix * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    // A copy into pageable memory runs at a few GB/s; through a pinned staging buffer the link runs at its own rate
+    // and the last hop is a host memcpy.
+    const size_t sz_bgr = npix * 3, sz_rad = radiance_out ? npix * 3 * sizeof(float) : 0;
+    const size_t sz_prim = primary_out ? npix * 2 * sizeof(int32_t) : 0, sz_pt = primary_t_out ? npix * sizeof(float) : 0;
+    const size_t off_rad = (sz_bgr + 255) / 256 * 256, off_prim = off_rad + (sz_rad + 255) / 256 * 256, off_pt = off_prim + (sz_prim + 255) / 256 * 256;
+    const size_t need = off_pt + sz_pt;
+    if (need > c->stage_alloc) {
+        if (c->h_stage) hipHostFree(c->h_stage);
+        c->h_stage = nullptr; c->stage_alloc = 0;
+        HIPCHK(c, hipHostMalloc(&c->h_stage, need, hipHostMallocDefault));
+        c->stage_alloc = need;
+    }
+    char* hs = (char*)c->h_stage;
+    HIPCHK(c, hipMemcpyAsync(hs, c->d_bgr, sz_bgr, hipMemcpyDeviceToHost, c->stream));
+    if (sz_rad) HIPCHK(c, hipMemcpyAsync(hs + off_rad, c->d_rad, sz_rad, hipMemcpyDeviceToHost, c->stream));
+    if (sz_prim) HIPCHK(c, hipMemcpyAsync(hs + off_prim, c->d_prim, sz_prim, hipMemcpyDeviceToHost, c->stream));
+    if (sz_pt) HIPCHK(c, hipMemcpyAsync(hs + off_pt, c->d_prim_t, sz_pt, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(bgr_out, hs, sz_bgr);
+    if (sz_rad) memcpy(radiance_out, hs + off_rad, sz_rad);
+    if (sz_prim) memcpy(primary_out, hs + off_prim, sz_prim);
+    if (sz_pt) memcpy(primary_t_out, hs + off_pt, sz_pt);
     if (stats) *stats = local;
     return T3D_OK;
 }
