@@ -1396,13 +1396,18 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
     // groups in order of their first triangle, triangles inside a group in their original order.
     struct Tri { int obj, face, shader; double n[3], nv0; };
     std::vector<Tri> tris((size_t)s->n_tris);
-    std::vector<int> group_of((size_t)s->n_tris, -1);
     std::vector<std::vector<int>> groups;
     std::map<std::tuple<long long, long long, long long, long long>, int> plane_index;
     std::vector<DevSphere> spheres;
     std::vector<float> obj_ior((size_t)s->n_objects);
     std::vector<char> seen((size_t)s->n_tris, 0);
     c->n_sphere_objs = c->n_light_objs = 0;
+    // Large scenes are traced through an LBVH over all triangles and spheres, built on the device; the plane groups
+    // of the brute-force loop are not built for them (every triangle stays where it is in the description).
+    int n_prims = s->n_tris;
+    for (int o = 0; o < s->n_objects; ++o) n_prims += s->obj_type[o] == T3D_OBJ_SPHERE || s->obj_type[o] == T3D_OBJ_LIGHT;
+    const bool want_bvh = n_prims >= 2 && (c->accel == T3D_ACCEL_LBVH || (c->accel == T3D_ACCEL_AUTO && n_prims > T3D_BRUTE_FORCE_MAX_PRIMS));
+    int n_owned = 0;
     for (int o = 0; o < s->n_objects; ++o) {
         obj_ior[o] = (float)s->obj_ior[o];
         int ty = s->obj_type[o];
@@ -1421,6 +1426,8 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
                 if (T.shader < 0 || T.shader >= s->n_shaders) { c->err = "t3d_upload_scene: triangle shader index out of range"; return T3D_E_INVALID; }
                 if (seen[t]) { c->err = "t3d_upload_scene: triangle ranges of two objects overlap"; return T3D_E_INVALID; }
                 seen[t] = 1;
+                ++n_owned;
+                if (want_bvh) continue;
                 int g = -1;
                 if (nn > 0) {
                     double len = sqrt(nn), off = T.nv0 / len;
@@ -1431,7 +1438,6 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
                     else g = it->second;
                 } else { g = (int)groups.size(); groups.emplace_back(); }  // degenerate triangle: never hit, own group
                 groups[g].push_back(t);
-                group_of[t] = g;
             }
         } else if (ty == T3D_OBJ_SPHERE || ty == T3D_OBJ_LIGHT) {
             DevSphere sp;
@@ -1444,9 +1450,7 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
             if (sp.is_light) c->n_light_objs++; else c->n_sphere_objs++;
         }
     }
-    int n_mesh_tris = 0;
-    for (auto& g : groups) n_mesh_tris += (int)g.size();
-    if (n_mesh_tris != s->n_tris) { c->err = "t3d_upload_scene: triangles not owned by any mesh object"; return T3D_E_INVALID; }
+    if (n_owned != s->n_tris) { c->err = "t3d_upload_scene: triangles not owned by any mesh object"; return T3D_E_INVALID; }
     // Device order of the groups: by the axis of the largest normal component (that axis is dropped for the
     // in-plane coordinates), groups of one axis in order of their first triangle; groups of more than 24
     // triangles are cut into pieces (the hit flags of a group are the bits of a float32 integer).
@@ -1506,6 +1510,14 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
             }
         }
         plane_first[G] = k;
+        if (want_bvh) {
+            for (int t = 0; t < s->n_tris; ++t) {
+                const Tri& T = tris[t];
+                tri_n[t] = make_float4((float)T.n[0], (float)T.n[1], (float)T.n[2], -(float)T.nv0 + 0.0f);
+                order[t] = t;
+                meta[t] = make_int4(T.obj, T.face, T.shader, t);
+            }
+        }
         // Parallelograms: when the first two triangles of a group share an edge and their other two corners are
         // opposite corners of a parallelogram, the second triangle's barycentrics are the mirror image of the
         // first one's (u' = 1 - u, v' = 1 - v, w' = -w, origin at the corner opposite the shared edge), and the
@@ -1558,9 +1570,6 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
         (rc = upload(c, &c->d_tri_n, tri_n)) || (rc = upload(c, &c->d_tri_meta, meta)) || (rc = upload(c, &c->d_spheres, spheres)) ||
         (rc = upload(c, &c->d_lights, lights)) || (rc = upload(c, &c->d_shaders, shaders)) || (rc = upload(c, &c->d_obj_ior, obj_ior)))
         return rc;
-    // Large scenes are traced through an LBVH over all triangles and spheres, built on the device.
-    const int n_prims = s->n_tris + (int)spheres.size();
-    const bool want_bvh = n_prims >= 2 && (c->accel == T3D_ACCEL_LBVH || (c->accel == T3D_ACCEL_AUTO && n_prims > T3D_BRUTE_FORCE_MAX_PRIMS));
     if (want_bvh) {
         // 3-D barycentric rows  a = (e2 x n) / |n|^2, b = (n x e1) / |n|^2 :  P - v0 = u e1 + v e2  (float64, rounded once)
         std::vector<float4> tri_ab((size_t)4 * (s->n_tris + 1), make_float4(0.f, 0.f, 0.f, 0.f));
