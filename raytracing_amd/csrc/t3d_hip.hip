@@ -404,6 +404,7 @@ __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0
 #ifndef T3D_BVH_WAVES
 #define T3D_BVH_WAVES 6   // waves per SIMD the traversal kernels are compiled for
 #endif
+#define BVH_DONE 0x7fffffff
 struct BvhCount {
     uint32_t nodes, tris, spheres, deep;
 };
@@ -416,7 +417,8 @@ struct BvhLane {
     float best;
     int prim, rank, back;
     int sp, top;   // top mirrors stack[sp - 1]: a pop uses it at once and only then fetches the entry below,
-    int node;      // so the private-memory read is off the critical path
+    int node;      // so the stack read is off the critical path; BVH_DONE: nothing left to visit
+    int pend;      // a leaf link (negative) met but not tested yet, 0: none
     bool lights, back_cull;
 };   // the stack is a separate array: inside the structure it would drag every field into private memory
 
@@ -429,7 +431,7 @@ __device__ __forceinline__ void bvh_begin(BvhLane& s, V3 o, V3 d, bool lights, b
     s.oi = mk(-o.x * s.inv.x, -o.y * s.inv.y, -o.z * s.inv.z);
     s.best = __builtin_inff();
     s.prim = -1; s.back = 0; s.rank = 0x7fffffff;
-    s.sp = 0; s.top = 0; s.node = 0;
+    s.sp = 0; s.top = 0; s.node = 0; s.pend = 0;
     s.lights = lights; s.back_cull = back_cull;
 }
 
@@ -439,7 +441,14 @@ __device__ __forceinline__ void bvh_begin(BvhLane& s, V3 o, V3 d, bool lights, b
 __device__ __forceinline__ bool bvh_step(const DevScene& sc, BvhLane& s, int* lds, int (&deep)[T3D_BVH_DEEP_STACK], BvhCount& bc,
                                          int* stack_overflow) {
     const V3 o = s.o, d = s.d, inv = s.inv, oi = s.oi;
-    if (s.node >= 0) {
+    auto pop = [&]() {
+        if (s.sp == 0) { s.node = BVH_DONE; return; }
+        s.node = s.top;
+        --s.sp;
+        const int e = s.sp > 0 ? s.sp - 1 : 0;
+        s.top = e < T3D_BVH_LDS_STACK ? lds[64 * e] : deep[e - T3D_BVH_LDS_STACK];
+    };
+    if (s.node >= 0 && s.node != BVH_DONE) {
         const float4* __restrict__ rec = sc.bvh.nodes + 4 * (size_t)s.node;
         const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
         bc.nodes++;
@@ -493,10 +502,20 @@ __device__ __forceinline__ bool bvh_step(const DevScene& sc, BvhLane& s, int* ld
                 }
             }
         }
-        if (tn[0] < __builtin_inff()) { s.node = ln[0]; return false; }
-    } else {
+        if (tn[0] < __builtin_inff()) s.node = ln[0];
+        else pop();
+    }
+    // A leaf is not tested at once.  The leaf code is issued for the whole wave whenever one lane needs it, and at any
+    // moment only a few lanes do: the link waits in the lane's pending slot while the lane goes on with its stack
+    // (against a best distance that may be one leaf out of date, which can only cost visits), and the leaves of
+    // all lanes are tested together as soon as one lane cannot go on without its own -- it met a second leaf, or
+    // its stack is empty.
+    if (s.node < 0 && s.pend == 0) { s.pend = s.node; pop(); }
+    const bool blocked = s.pend != 0 && (s.node < 0 || s.node == BVH_DONE);
+    if (__ballot(blocked) != 0ull && s.pend != 0) {
         // all rows are requested at once: one memory latency per leaf instead of two on the hit path
-        const float4* __restrict__ rec = sc.bvh.leaves + 4 * (size_t)(~s.node);
+        const float4* __restrict__ rec = sc.bvh.leaves + 4 * (size_t)(~s.pend);
+        s.pend = 0;
         const float4 rn = rec[0], ra = rec[1], rb = rec[2], rm = rec[3];
         const int p = __float_as_int(rm.x), rk = __float_as_int(rm.w);  // rk: place in the scene's object / face order, spheres last
         if (__float_as_int(rm.y) == 0) {
@@ -536,14 +555,8 @@ __device__ __forceinline__ bool bvh_step(const DevScene& sc, BvhLane& s, int* ld
             }
         }
     }
-    if (s.sp == 0) return true;
-    s.node = s.top;
-    --s.sp;
-    {
-        const int e = s.sp > 0 ? s.sp - 1 : 0;
-        s.top = e < T3D_BVH_LDS_STACK ? lds[64 * e] : deep[e - T3D_BVH_LDS_STACK];
-    }
-    return false;
+    if (s.node < 0 && s.pend == 0) { s.pend = s.node; pop(); }   // the leaf that blocked the lane
+    return s.node == BVH_DONE && s.pend == 0;
 }
 
 // Closest hit of one ray per lane; every lane runs until its own ray is finished.
