@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cornell_1080p_b4")
     ap.add_argument("--partition", default="interleaved", choices=["interleaved", "bands"])
+    ap.add_argument("--accel", default="auto", choices=["auto", "brute", "lbvh"], help="closest-hit structure (auto: by scene size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-row-step", type=int, default=0, help="CPU baseline renders every n-th row (0: every row for the headline workload, one row per thread otherwise)")
     args = ap.parse_args()
@@ -114,6 +115,7 @@ def main():
     flat, options = get_flat_workload(args.workload)
     seed = 0
     ctx = _native.Context(local_rank)
+    ctx.set_accel(args.accel)
     ctx.upload(flat)
     H, W = options["height"], options["width"]
     tile = partition_rows(H, world, rank, args.partition)
