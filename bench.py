@@ -166,7 +166,8 @@ def main():
         level_s = last["ms_k_level"] * 1e-3
         achieved = flops / level_s / 1e12 if level_s > 0 else 0.0
         line = {
-            "metric": "Mrays/s (primary+secondary closest-hit queries), Cornell 1080p 4 bounces",
+            "metric": "Mrays/s (primary+secondary closest-hit queries), " +
+                      ("Cornell 1080p 4 bounces" if args.workload == "cornell_1080p_b4" else args.workload),
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
