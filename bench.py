@@ -120,7 +120,11 @@ def main():
     H, W = options["height"], options["width"]
     tile = partition_rows(H, world, rank, args.partition)
     out = torch.empty((tile.nrows, W, 3), dtype=torch.uint8, device=device)
-    stream = torch.cuda.current_stream(device).cuda_stream
+    # an explicit stream: a null handle would mean "the context's own stream" to the library, and the gather that
+    # follows every render on torch's current stream has to be ordered behind it
+    torch_stream = torch.cuda.Stream(device)
+    torch.cuda.set_stream(torch_stream)
+    stream = torch_stream.cuda_stream
 
     def step(want_stats):
         st = ctx.render_rows_device(options, seed, tile.row0, tile.nrows, out.data_ptr(), stream=stream,

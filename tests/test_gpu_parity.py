@@ -399,3 +399,36 @@ def test_many_lights(gpu_ctx, oracle_mod):
     ref = oracle_mod.render(flat, opt, seed=2)
     check_against_oracle(out, ref, oracle_mod.primary_fragility(flat, opt))
     assert out["stats"]["shadow_queries"] == len(flat.light_strength) * out["stats"]["nodes"]
+
+
+def test_device_outputs_follow_the_callers_stream(gpu_ctx):
+    """Asynchronous device-output calls on an explicit stream: every call's output is complete for what the caller
+    queues behind it on that stream, call after call into the same buffers; with an odd row count, a row stride and an
+    offset as one rank of a multi-GPU run has them."""
+    import torch
+    flat = flat_for("config2_cornell_light.json")
+    gpu_ctx.set_accel("auto")
+    gpu_ctx.upload(flat)
+    opt = dict(width=320, height=243, bounces=3, samples=2)
+    dev = torch.device("cuda", 0)
+    torch_stream = torch.cuda.Stream(dev)   # a null handle would mean the context's own stream
+    torch.cuda.set_stream(torch_stream)
+    stream = torch_stream.cuda_stream
+    for row0, nrows, stride in ((0, 243, 1), (1, 121, 2)):
+        gpu_ctx.set_timing(False)
+        bgr = torch.zeros((nrows, 320, 3), dtype=torch.uint8, device=dev)
+        rad = torch.zeros((nrows, 320, 3), dtype=torch.float32, device=dev)
+        frames = []
+        for seed in (9, 10, 11, 9):     # four calls into the same buffers, a copy queued after each
+            gpu_ctx.render_rows_device(opt, seed, row0, nrows, bgr.data_ptr(), radiance_ptr=rad.data_ptr(), stream=stream,
+                                       want_stats=False, row_stride=stride)
+            frames.append((bgr.clone(), rad.clone()))
+        st = gpu_ctx.last_call_stats()
+        torch.cuda.synchronize()
+        gpu_ctx.set_timing(True)
+        frames = [(a.cpu().numpy(), b.cpu().numpy()) for a, b in frames]
+        for seed, (got_bgr, got_rad) in zip((9, 10, 11, 9), frames):
+            host = gpu_ctx.render_rows(opt, seed=seed, row0=row0, nrows=nrows, row_stride=stride, want_radiance=True)
+            assert np.array_equal(host["bgr"], got_bgr) and np.array_equal(host["radiance"], got_rad)
+        assert not np.array_equal(frames[0][0], frames[1][0])          # the seeds do differ
+        assert st["rays_api"] == host["stats"]["rays_api"] and st["queries"] == host["stats"]["queries"]

@@ -14,7 +14,9 @@ flat, opt = get_flat_workload(workload)
 ctx = _native.Context(0); ctx.upload(flat)
 H, W = opt["height"], opt["width"]
 dev = torch.device("cuda", 0)
-stream = torch.cuda.current_stream(dev).cuda_stream
+torch_stream = torch.cuda.Stream(dev)
+torch.cuda.set_stream(torch_stream)
+stream = torch_stream.cuda_stream
 for n in ([int(a) for a in args] or [1, 2, 4, 8]):
     rows = H // n
     out = torch.empty((rows, W, 3), dtype=torch.uint8, device=dev)
