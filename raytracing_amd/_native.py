@@ -34,6 +34,25 @@ class Node(C.Structure):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """A PyTorch-ROCm wheel carries its own libamdhip64.so.7.  A process can hold one HIP runtime only: whichever copy
+    is loaded first serves both users, and torch finds no GPU when it is made to run on the system's copy.  So when
+    such a wheel is installed (it need not be imported, and is not imported here) its copy is loaded first; without
+    one, the library's own run path (/opt/rocm/lib) applies."""
+    if os.environ.get("T3D_SYSTEM_HIP_RUNTIME"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except (ImportError, OSError, ValueError):
+        pass
+
+
 def load():
     """Load libt3d_hip.so once and declare its prototypes."""
     global _lib
@@ -42,6 +61,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise NativeError(f"{LIB_PATH} not found: build it with `make -C raytracing_amd/csrc` "
                           "(or python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+    _share_hip_runtime_with_torch()
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:

@@ -5,10 +5,6 @@ import sys
 import numpy as np
 import pytest
 
-try:    # before the HIP library is loaded: torch brings its own copy of the HIP runtime and must be the first to load it
-    import torch  # noqa: F401
-except ImportError:
-    pass
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
