@@ -196,3 +196,25 @@ def test_deep_traversal_stack(gpu_ctx, oracle_mod):
     # single-ray entry point through the same stack
     hit = gpu_ctx.closest_hits([[0.1, 0.2, -28.8]], [[0.0, 0.0, 1.0]], True, True)
     assert hit["face"][0] == 0 and abs(hit["t"][0] - 18.8) < 1e-4
+
+
+def test_scene_without_lights_through_lbvh(lbvh_ctx, oracle_mod):
+    """No Light object and no emissive face: no shadow rays at all (the shadow kernel is not launched)."""
+    import os
+    from conftest import SCENES
+    from raytracing_amd.flatten import flatten_scene
+    from raytracing_amd.scene import Scene
+    scene = Scene.fromJSON(os.path.join(SCENES, "config2_suzanne.json"))
+    scene.objects = [o for o in scene.objects if o.type != "light"]
+    for o in scene.objects:
+        for sh in getattr(o, "shaders", None) or []:
+            sh.emissionStrength = 0
+    flat = flatten_scene(scene)
+    assert len(flat.light_strength) == 0
+    lbvh_ctx.upload(flat)
+    opt = dict(width=96, height=54, bounces=3, samples=2)
+    out = lbvh_ctx.render_rows(opt, seed=4, want_radiance=True, want_primary=True)
+    assert out["stats"]["shadow_queries"] == 0 and out["stats"]["aabb_tests"] > 0
+    ref = oracle_mod.render(flat, opt, seed=4)
+    frag = oracle_mod.primary_fragility(flat, opt)
+    check_against_oracle(out, ref, frag)
