@@ -380,8 +380,10 @@ def test_plane_group_corner_cases(gpu_ctx, oracle_mod):
     gpu_ctx.set_accel("auto")
 
 
-def test_many_lights(gpu_ctx, oracle_mod):
-    """Twelve Light objects plus the emissive panel: many shadow rays per node through the per-wave ring."""
+@pytest.mark.parametrize("accel", ["brute", "lbvh"])
+def test_many_lights(gpu_ctx, oracle_mod, accel):
+    """Twelve Light objects plus the emissive panel: many shadow rays per node, through the per-wave ring of the
+    brute-force kernel and through the shadow kernel of the LBVH path."""
     from raytracing_amd.flatten import flatten_scene
     from raytracing_amd.scene import Light, Vec3
     from raytracing_amd.workloads import cornell_scene
@@ -392,8 +394,9 @@ def test_many_lights(gpu_ctx, oracle_mod):
         Light(scene=scene, name=f"extra{i}", position=Vec3(float(p[0]), float(p[1]), float(1.0 + p[2])), strength=float(rng.uniform(0.1, 0.6)))
     flat = flatten_scene(scene)
     assert len(flat.light_strength) >= 13
-    gpu_ctx.set_accel("auto")
+    gpu_ctx.set_accel(accel)
     gpu_ctx.upload(flat)
+    gpu_ctx.set_accel("auto")
     opt = dict(width=100, height=60, bounces=3, samples=1, ambient=(32, 32, 32))
     out = gpu_ctx.render_rows(opt, seed=2, want_radiance=True, want_primary=True)
     ref = oracle_mod.render(flat, opt, seed=2)
