@@ -110,11 +110,14 @@ def test_full_size_frame_properties(gpu_ctx, oracle_mod):
     check_against_oracle(sub, ref, frag)
 
 
-def test_trace_pixel_matches_oracle(gpu_ctx, oracle_mod):
+@pytest.mark.parametrize("accel", ["brute", "lbvh"])
+def test_trace_pixel_matches_oracle(gpu_ctx, oracle_mod, accel):
     g, meta = load_golden("g2_cornell_80x60_b4_s2_keyed")
     flat = flat_for(meta["scene"])
     opt, seed = meta["options"], meta["seed"]
+    gpu_ctx.set_accel(accel)
     gpu_ctx.upload(flat)
+    gpu_ctx.set_accel("auto")
     ref = oracle_mod.render(flat, opt, seed=seed, want_nodes=True)
     by_key = {}
     for n in ref["nodes"]:
