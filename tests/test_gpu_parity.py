@@ -334,8 +334,9 @@ def test_bench_line_contract():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "rows" in c["sample"]
 
 
-def test_plane_group_corner_cases(gpu_ctx, oracle_mod):
-    """One plane of 60 triangles (cut into pieces of 24), a duplicated triangle with another shader (the first one
+@pytest.mark.parametrize("accel", ["brute", "lbvh"])
+def test_plane_group_corner_cases(gpu_ctx, oracle_mod, accel):
+    """Both closest-hit structures.  One plane of 60 triangles (cut into pieces of 24), a duplicated triangle with another shader (the first one
     tested must win), a degenerate triangle, a lone triangle, parallelograms and non-parallelogram pairs."""
     from raytracing_amd.flatten import flatten_scene
     from raytracing_amd.scene import RGB, Camera, Light, Mesh, Object, Scene, Shader, Vec3
@@ -370,7 +371,7 @@ def test_plane_group_corner_cases(gpu_ctx, oracle_mod):
     Light(s, position=Vec3(0.3, 3, 4.5), strength=1.2)
     Camera(s, position=Vec3(0.113, 0.657, -1.9))
     flat = flatten_scene(s)
-    gpu_ctx.set_accel("brute")
+    gpu_ctx.set_accel(accel)
     gpu_ctx.upload(flat)
     for opt in (dict(width=120, height=90, bounces=0), dict(width=120, height=90, bounces=3, samples=2)):
         out = gpu_ctx.render_rows(opt, seed=9, want_radiance=True, want_primary=True)
