@@ -129,6 +129,7 @@ struct RenderParams {
     int want_debug;  // record t3d_node entries (t3d_trace_pixel)
     int px0, py0, sample0;  // single-sample mode (t3d_trace_pixel / t3d_trace_ray): key of the random numbers
     int single;             // 0 image band, 1 one pixel sample (camera ray), 2 one explicit ray
+    int tiled;              // level 0 walks the band in 16 x 8 pixel tiles (width % 16 == 0, rows % 8 == 0)
     float ray_o[3], ray_d[3], ray_ior;  // single == 2: the initial ray (unit direction) ...
     int ray_obj;                        // ... and the object it travels inside (-1 none)
 };
@@ -853,6 +854,13 @@ __device__ __forceinline__ void load_ray(const DevScene& sc, const RenderParams&
     in.ps = 0; in.heap = 1; in.pixel_hash = 0; in.px = 0; in.py = 0; in.smp = 0;
     if (in.active) {
         if (LEVEL0) {
+            if (rp.tiled) {
+                // work order: 16 x 8 pixel tiles, so that the 128 rays of a round stay close together
+                const int wpix = in.i / rp.samples, wsmp = in.i - wpix * rp.samples;
+                const int t = wpix >> 7, within = wpix & 127, tiles_x = rp.width >> 4;
+                const int ty = t / tiles_x, tx = t - ty * tiles_x;
+                in.i = (((ty << 3) + (within >> 4)) * rp.width + (tx << 4) + (within & 15)) * rp.samples + wsmp;
+            }
             in.ps = (uint32_t)in.i;
             in.parent = in.i;
             int pix = in.i / rp.samples;
@@ -1765,6 +1773,7 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
     rp.cap = (int)c->cap_alloc;
     rp.n0 = (int)n0;
     rp.resident_waves = c->n_sm * 16;   // 4 waves per SIMD at this kernel's register count
+    rp.tiled = !single && o->width % 16 == 0 && nrows % 8 == 0;
     if (single) {
         rp.single = single->single; rp.px0 = single->px0; rp.py0 = single->py0; rp.sample0 = single->sample0; rp.want_debug = 1;
         for (int k = 0; k < 3; ++k) { rp.ray_o[k] = single->ray_o[k]; rp.ray_d[k] = single->ray_d[k]; }
