@@ -102,14 +102,14 @@ typedef struct t3d_stats {
     uint64_t aabb_tests;     /* ray-box tests executed                                               */
     uint64_t nodes;          /* shaded trace-tree nodes (emitter leaves are folded into the parent)  */
     uint64_t launches;       /* kernel launches issued                                               */
-    uint64_t n_k_level;      /* launches of k_level, the closest-hit kernel (one per tree level)     */
+    uint64_t n_k_level;      /* tree levels traced (one k_level launch each; LBVH scenes: three kernels) */
     double ms_device;        /* device time of the whole call (HIP events on the launch stream)      */
-    double ms_k_level;       /* sum of the k_level launch durations                                  */
+    double ms_k_level;       /* time spent tracing the levels (k_level, or the three LBVH kernels)   */
     double ms_resolve;       /* colour resolve + image store                                         */
     /* per tree level (0 = primary rays), summed over the bands of the call; levels above bounces stay 0 */
     uint64_t level_rays[T3D_STATS_MAX_LEVELS];   /* tree rays traced at the level                    */
     uint64_t level_nodes[T3D_STATS_MAX_LEVELS];  /* shaded nodes created at the level                */
-    double level_ms[T3D_STATS_MAX_LEVELS];       /* duration of the level's k_level launch           */
+    double level_ms[T3D_STATS_MAX_LEVELS];       /* time spent tracing the level                     */
     uint64_t bvh_deep_pushes; /* LBVH path: traversal-stack entries that did not fit the per-lane LDS part   */
 } t3d_stats;
 

@@ -1801,7 +1801,7 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
     const int* pfirst = (const int*)c->d_plane_first;
     const float4* uv = (const float4*)c->d_tri_uv;
     const DevSphere* sph = (const DevSphere*)c->d_spheres;
-    // the traversal kernels of the LBVH path keep as many waves as the device holds, each with a fixed share of the rays
+    // the traversal kernels of the LBVH path keep as many waves as the device holds; they take their rays in chunks from counters
     auto resident_blocks_for = [&](size_t n) {
         size_t b = (n + T3D_BLOCK - 1) / T3D_BLOCK, mx = (size_t)c->n_sm * T3D_BVH_WAVES;
         b = b > mx ? mx : b;
