@@ -1309,6 +1309,7 @@ struct t3d_ctx {
     bool last_timed = true;
     bool last_valid = false; int last_levels = 0; size_t last_n0 = 0; int last_lights = 1; uint64_t last_launches = 0;
     hipStream_t last_stream = nullptr;
+    bool counters_on_host = false;   // h_cnt holds (or is about to receive) the counters of the most recent band
 };
 
 static thread_local std::string g_create_err;
@@ -1870,7 +1871,9 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
     }
     HIPCHK(c, tick());  // last event: end of the call
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
+    // a call that stays asynchronous leaves its counters on the device until somebody asks (t3d_last_call_stats)
+    c->counters_on_host = stats || single;
+    if (c->counters_on_host) HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
     c->last_timed = c->timing;
     c->last_levels = levels; c->last_n0 = n0; c->last_lights = o->lights; c->last_launches = launches; c->last_stream = st;
     c->last_valid = true;
@@ -1954,6 +1957,10 @@ extern "C" int t3d_last_call_stats(t3d_ctx* c, t3d_stats* stats) {
     if (!c || !stats) return T3D_E_INVALID;
     if (!c->last_valid) { c->err = "no render call to report on"; return T3D_E_INVALID; }
     HIPCHK(c, hipSetDevice(c->device));
+    if (!c->counters_on_host) {
+        HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, c->last_stream));
+        c->counters_on_host = true;
+    }
     HIPCHK(c, hipStreamSynchronize(c->last_stream));
     memset(stats, 0, sizeof *stats);
     if (c->h_cnt->overflow) { c->err = "trace tree did not fit the node buffers"; return T3D_E_CAPACITY; }
