@@ -1209,7 +1209,10 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_resolve(DevScene sc, RenderParams
 // k_finish: RGB.mean + clamp + BGR8 (T3DE.py:401-415, T3DR.py:1219-1221)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(T3D_BLOCK) void k_finish(RenderParams rp, const float4* __restrict__ sample_color,
-                                                      uint8_t* __restrict__ bgr, float* __restrict__ radiance) {
+                                                      uint8_t* __restrict__ bgr, float* __restrict__ radiance,
+                                                      uint4* __restrict__ zero, int n_zero) {
+    // the counters of the NEXT band (the context has two sets, used in turn): cleared here, a band needs no fill of its own
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_zero; i += gridDim.x * blockDim.x) zero[i] = make_uint4(0u, 0u, 0u, 0u);
     const int npix = rp.nrows * rp.width;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
         float r = 0, g = 0, b = 0;
@@ -1296,7 +1299,10 @@ struct t3d_ctx {
     hipEvent_t ev_shadowed[T3D_MAX_BOUNCES + 2] = {};  // shadow rays of level d done
     size_t n0_alloc = 0;
     float4* d_sample_color = nullptr;
-    Counters* d_cnt = nullptr;
+    Counters* d_cnt = nullptr;            // counters of the current / most recent band: one of the pair
+    Counters* d_cnt_pair[2] = {nullptr, nullptr};
+    int cnt_idx = 0;                      // d_cnt_pair[cnt_idx] is all zero between bands ...
+    bool cnt_clean = true;                // ... as long as this says so
     Counters* h_cnt = nullptr;  // pinned
     PaddedCount* d_fetch = nullptr;  // LBVH path: chunk counters of the traversal kernels, [level][trace, shadow][shard]
     // staging for host outputs
@@ -1353,7 +1359,8 @@ extern "C" int t3d_create(int device, t3d_ctx** out) {
     hipStreamCreateWithFlags(&c->shadow_stream, hipStreamNonBlocking);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_sm = prop.multiProcessorCount;
-    if (hipMalloc((void**)&c->d_cnt, sizeof(Counters)) != hipSuccess ||
+    if (hipMalloc((void**)&c->d_cnt_pair[0], sizeof(Counters)) != hipSuccess || hipMalloc((void**)&c->d_cnt_pair[1], sizeof(Counters)) != hipSuccess ||
+        hipMemset(c->d_cnt_pair[0], 0, sizeof(Counters)) != hipSuccess || hipMemset(c->d_cnt_pair[1], 0, sizeof(Counters)) != hipSuccess ||
         hipMalloc((void**)&c->d_fetch, sizeof(PaddedCount) * (T3D_MAX_BOUNCES + 2) * 2 * T3D_SHARDS) != hipSuccess ||
         hipHostMalloc((void**)&c->h_cnt, sizeof(Counters), hipHostMallocDefault) != hipSuccess) {
         g_create_err = "t3d_create: counter allocation failed";
@@ -1387,7 +1394,7 @@ extern "C" void t3d_destroy(t3d_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     free_scene(c); free_work(c);
-    hipFree(c->d_sample_color); hipFree(c->d_cnt); hipFree(c->d_fetch); hipHostFree(c->h_cnt);
+    hipFree(c->d_sample_color); hipFree(c->d_cnt_pair[0]); hipFree(c->d_cnt_pair[1]); hipFree(c->d_fetch); hipHostFree(c->h_cnt);
     hipFree(c->d_bgr); hipFree(c->d_rad); hipFree(c->d_prim); hipFree(c->d_prim_t);
     if (c->h_stage) hipHostFree(c->h_stage);
     for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
@@ -1781,7 +1788,12 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
         rp.ray_ior = single->ray_ior; rp.ray_obj = single->ray_obj;
     }
 
-    HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), st));
+    static_assert(sizeof(Counters) % sizeof(uint4) == 0, "k_finish clears the counters in 16-byte pieces");
+    c->d_cnt = c->d_cnt_pair[c->cnt_idx];               // all zero: cleared by the band before (or at creation) ...
+    if (!c->cnt_clean) HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), st));   // ... unless that band was cut short
+    Counters* next_cnt = c->d_cnt_pair[c->cnt_idx ^ 1];
+    c->cnt_idx ^= 1;
+    c->cnt_clean = false;
     if (c->use_bvh) HIPCHK(c, hipMemsetAsync(c->d_fetch, 0, sizeof(PaddedCount) * (size_t)levels * 2 * T3D_SHARDS, st));
     TraceOut out{c->d_sample_color, d_prim, d_prim_t, d_dbg, dbg_cap};
     const int max_blocks = c->n_sm * 8;
@@ -1866,9 +1878,13 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
         launches++;
     }
     if (!single) {
-        hipLaunchKernelGGL(k_finish, dim3(blocks_for((size_t)nrows * o->width)), dim3(T3D_BLOCK), 0, st, rp, c->d_sample_color, d_bgr, d_rad);
+        hipLaunchKernelGGL(k_finish, dim3(blocks_for((size_t)nrows * o->width)), dim3(T3D_BLOCK), 0, st, rp, c->d_sample_color, d_bgr, d_rad,
+                           (uint4*)next_cnt, (int)(sizeof(Counters) / sizeof(uint4)));
         launches++;
+    } else {
+        HIPCHK(c, hipMemsetAsync(next_cnt, 0, sizeof(Counters), st));
     }
+    c->cnt_clean = true;
     HIPCHK(c, tick());  // last event: end of the call
     HIPCHK(c, hipGetLastError());
     // a call that stays asynchronous leaves its counters on the device until somebody asks (t3d_last_call_stats)
