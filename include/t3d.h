@@ -8,7 +8,9 @@
  * negative T3D_E_* code; t3d_last_error() gives the text; no exception crosses the ABI; all
  * pointers are plain host pointers unless the name says "device"; the library copies what it
  * needs during the call, the caller keeps ownership of everything it passes in.
- * One host thread per context.
+ * One host thread per context, and one stream at a time: all calls of a context share its work buffers and
+ * counters, so a caller that moves from one stream to another (or from t3d_render_rows_device on its own stream
+ * to the entry points that use the context's stream) lets the first stream finish before it does.
  */
 #ifndef T3D_H
 #define T3D_H
