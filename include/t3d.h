@@ -215,7 +215,8 @@ int t3d_last_call_stats(t3d_ctx* ctx, t3d_stats* stats);
  * Per-kernel timing on (default) / off.  When on, an event is recorded after every k_level launch so
  * that t3d_stats::ms_k_level and ms_resolve are filled; each event costs a few microseconds of stream
  * idle time between two launches.  When off only ms_device (whole call) is measured and the other two
- * stay 0.  No counterpart in the reference.
+ * stay 0; a call that is also asynchronous (no `stats`) records no event at all and reports ms_device 0.
+ * No counterpart in the reference.
  */
 int t3d_set_timing(t3d_ctx* ctx, int per_kernel);
 

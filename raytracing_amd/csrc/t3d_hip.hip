@@ -1313,6 +1313,7 @@ struct t3d_ctx {
     // the most recent band, for t3d_last_call_stats
     bool timing = true;       // record an event after every k_level launch (t3d_set_timing)
     bool last_timed = true;
+    bool last_events = true;   // the band recorded its start and end
     bool last_valid = false; int last_levels = 0; size_t last_n0 = 0; int last_lights = 1; uint64_t last_launches = 0;
     hipStream_t last_stream = nullptr;
     bool counters_on_host = false;   // h_cnt holds (or is about to receive) the counters of the most recent band
@@ -1713,7 +1714,7 @@ static void fill_stats(t3d_ctx* c, t3d_stats* stats) {
     const int levels = c->last_levels;
     const int n_ev = c->last_timed ? levels + 2 : 2;
     float ms = 0;
-    hipEventElapsedTime(&ms, c->ev[0], c->ev[n_ev - 1]);
+    if (c->last_events) hipEventElapsedTime(&ms, c->ev[0], c->ev[n_ev - 1]);
     stats->ms_device += ms;
     if (c->last_timed) {
         for (int d = 0; d < levels; ++d) {
@@ -1823,7 +1824,9 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
     };
     // per-level timing wants the levels one after the other
     const bool overlap = c->use_bvh && !c->timing && !single;
-    HIPCHK(c, tick());  // ev[0]: start of the call
+    // a call that stays asynchronous and is not being timed gets no events at all: each one is a stop in the stream
+    const bool events = c->timing || stats || single;
+    if (events) HIPCHK(c, tick());  // ev[0]: start of the call
     for (int d = 0; d < levels; ++d) {
         RayRec* in = c->d_rays[d & 1];
         RayRec* outq = c->d_rays[(d + 1) & 1];
@@ -1885,12 +1888,13 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
         HIPCHK(c, hipMemsetAsync(next_cnt, 0, sizeof(Counters), st));
     }
     c->cnt_clean = true;
-    HIPCHK(c, tick());  // last event: end of the call
+    if (events) HIPCHK(c, tick());  // last event: end of the call
     HIPCHK(c, hipGetLastError());
     // a call that stays asynchronous leaves its counters on the device until somebody asks (t3d_last_call_stats)
     c->counters_on_host = stats || single;
     if (c->counters_on_host) HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
     c->last_timed = c->timing;
+    c->last_events = events;
     c->last_levels = levels; c->last_n0 = n0; c->last_lights = o->lights; c->last_launches = launches; c->last_stream = st;
     c->last_valid = true;
     if (!stats && !single) return T3D_OK;  // asynchronous use: overflow is not checked
