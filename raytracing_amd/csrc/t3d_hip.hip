@@ -581,7 +581,17 @@ struct TraceOut {
     float* primary_t;      // [npix] or null
     t3d_node* dbg;         // debug records or null
     int dbg_cap;
+    uint8_t* bgr;          // one sample per pixel: a finished sample is a finished pixel and goes straight to the
+    float* radiance;       // outputs (bgr null otherwise; radiance may be null)
 };
+
+// A pixel from the sum of its samples: floor-mean, clamp, BGR8 (T3DE.py:401-415, T3DR.py:1219-1221)
+__device__ __forceinline__ void store_pixel(uint8_t* __restrict__ bgr, float* __restrict__ radiance, int p, float r, float g, float b, float n) {
+    const float inv = 1.0f / n;
+    if (radiance) { radiance[3 * p] = r * inv; radiance[3 * p + 1] = g * inv; radiance[3 * p + 2] = b * inv; }
+    const float fr = fminf(floorf(r / n), 255.0f), fg = fminf(floorf(g / n), 255.0f), fb = fminf(floorf(b / n), 255.0f);
+    bgr[3 * p] = (uint8_t)fb; bgr[3 * p + 1] = (uint8_t)fg; bgr[3 * p + 2] = (uint8_t)fr;
+}
 
 __device__ __forceinline__ void camera_ray(const DevCamera& cam, const RenderParams& rp, int px, int py, V3& o, V3& d) {
     // pixelToVector (T3DR.py:528-542): pixel corner on the image plane, rotated, translated
@@ -729,7 +739,8 @@ __device__ __forceinline__ void process_ray(const DevScene& sc, const DevSphere*
     if (in.active && (!hit || emitter)) {
         if (LEVEL0) {
             V3 c = hit ? emit : mk(rp.ambient[0], rp.ambient[1], rp.ambient[2]);  // T3DR.py:1006-1007
-            out.sample_color[in.i] = make_float4(c.x, c.y, c.z, 0.0f);
+            if (out.bgr) store_pixel(out.bgr, out.radiance, in.i, c.x, c.y, c.z, 1.0f);
+            else out.sample_color[in.i] = make_float4(c.x, c.y, c.z, 0.0f);
         } else if (hit) {
             float4* slot = in.side ? pool.d : pool.c;
             *(float3*)&slot[in.parent] = make_float3(emit.x * att_parent, emit.y * att_parent, emit.z * att_parent);
@@ -1165,7 +1176,11 @@ __global__ __launch_bounds__(T3D_BLOCK, T3D_BVH_WAVES) void k_bvh_shadow(DevScen
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(T3D_BLOCK) void k_resolve(DevScene sc, RenderParams rp, int level, NodePool pool,
                                                        const Counters* __restrict__ cnt, float4* sample_color,
-                                                       t3d_node* dbg, int dbg_cap) {
+                                                       t3d_node* dbg, int dbg_cap, uint8_t* __restrict__ bgr, float* __restrict__ radiance,
+                                                       uint4* __restrict__ zero, int n_zero) {
+    // level 0 also clears the counters of the NEXT band (the context has two sets, used in turn): a band needs no fill
+    if (level == 0)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_zero; i += gridDim.x * blockDim.x) zero[i] = make_uint4(0u, 0u, 0u, 0u);
     const size_t node_base = (size_t)level * rp.cap;
     const int shard_cap = rp.cap / T3D_SHARDS;
     const int lane = threadIdx.x & 63;
@@ -1196,7 +1211,8 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_resolve(DevScene sc, RenderParams
             if (di >= 0 && di < dbg_cap) { dbg[di].color[0] = res[0]; dbg[di].color[1] = res[1]; dbg[di].color[2] = res[2]; }
         }
         if (level == 0) {
-            sample_color[parent] = make_float4(res[0], res[1], res[2], 0.0f);
+            if (bgr) store_pixel(bgr, radiance, parent, res[0], res[1], res[2], 1.0f);
+            else sample_color[parent] = make_float4(res[0], res[1], res[2], 0.0f);
         } else {
             const float att = c.w;
             float4* slot = side ? pool.d : pool.c;
@@ -1209,10 +1225,7 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_resolve(DevScene sc, RenderParams
 // k_finish: RGB.mean + clamp + BGR8 (T3DE.py:401-415, T3DR.py:1219-1221)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(T3D_BLOCK) void k_finish(RenderParams rp, const float4* __restrict__ sample_color,
-                                                      uint8_t* __restrict__ bgr, float* __restrict__ radiance,
-                                                      uint4* __restrict__ zero, int n_zero) {
-    // the counters of the NEXT band (the context has two sets, used in turn): cleared here, a band needs no fill of its own
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_zero; i += gridDim.x * blockDim.x) zero[i] = make_uint4(0u, 0u, 0u, 0u);
+                                                      uint8_t* __restrict__ bgr, float* __restrict__ radiance) {
     const int npix = rp.nrows * rp.width;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
         float r = 0, g = 0, b = 0;
@@ -1220,11 +1233,7 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_finish(RenderParams rp, const flo
             float4 c = sample_color[(size_t)p * rp.samples + k];
             r += c.x; g += c.y; b += c.z;
         }
-        float inv = 1.0f / (float)rp.samples;
-        if (radiance) { radiance[3 * p] = r * inv; radiance[3 * p + 1] = g * inv; radiance[3 * p + 2] = b * inv; }
-        float n = (float)rp.samples;
-        float fr = fminf(floorf(r / n), 255.0f), fg = fminf(floorf(g / n), 255.0f), fb = fminf(floorf(b / n), 255.0f);
-        bgr[3 * p] = (uint8_t)fb; bgr[3 * p + 1] = (uint8_t)fg; bgr[3 * p + 2] = (uint8_t)fr;
+        store_pixel(bgr, radiance, p, r, g, b, (float)rp.samples);
     }
 }
 
@@ -1796,7 +1805,9 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
     c->cnt_idx ^= 1;
     c->cnt_clean = false;
     if (c->use_bvh) HIPCHK(c, hipMemsetAsync(c->d_fetch, 0, sizeof(PaddedCount) * (size_t)levels * 2 * T3D_SHARDS, st));
-    TraceOut out{c->d_sample_color, d_prim, d_prim_t, d_dbg, dbg_cap};
+    // one sample per pixel: the kernels that finish a sample write the pixel themselves, and k_finish is not launched
+    const bool direct = !single && rp.samples == 1;
+    TraceOut out{c->d_sample_color, d_prim, d_prim_t, d_dbg, dbg_cap, direct ? d_bgr : nullptr, direct ? d_rad : nullptr};
     const int max_blocks = c->n_sm * 8;
     auto blocks_for = [&](size_t n) { size_t b = (n + T3D_BLOCK - 1) / T3D_BLOCK; return (int)(b < 1 ? 1 : (b > (size_t)max_blocks ? (size_t)max_blocks : b)); };
     // grids of the sharded kernels hold a multiple of T3D_SHARDS waves
@@ -1877,15 +1888,12 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
         for (int d = levels >= 2 ? levels - 2 : 0; d < levels; ++d) HIPCHK(c, hipStreamWaitEvent(st, c->ev_shadowed[d], 0));
     for (int d = levels - 1; d >= 0; --d) {
         hipLaunchKernelGGL(k_resolve, dim3(single ? (int)grid_unit : trace_blocks_for(c->cap_alloc)), dim3(T3D_BLOCK), 0, st, c->sc, rp, d, c->pool, c->d_cnt,
-                           c->d_sample_color, d_dbg, dbg_cap);
+                           c->d_sample_color, d_dbg, dbg_cap, out.bgr, out.radiance, (uint4*)next_cnt, (int)(sizeof(Counters) / sizeof(uint4)));
         launches++;
     }
-    if (!single) {
-        hipLaunchKernelGGL(k_finish, dim3(blocks_for((size_t)nrows * o->width)), dim3(T3D_BLOCK), 0, st, rp, c->d_sample_color, d_bgr, d_rad,
-                           (uint4*)next_cnt, (int)(sizeof(Counters) / sizeof(uint4)));
+    if (!single && !direct) {
+        hipLaunchKernelGGL(k_finish, dim3(blocks_for((size_t)nrows * o->width)), dim3(T3D_BLOCK), 0, st, rp, c->d_sample_color, d_bgr, d_rad);
         launches++;
-    } else {
-        HIPCHK(c, hipMemsetAsync(next_cnt, 0, sizeof(Counters), st));
     }
     c->cnt_clean = true;
     if (events) HIPCHK(c, tick());  // last event: end of the call
