@@ -21,8 +21,8 @@ starts = [i for i, r in enumerate(rows) if short(r["Kernel_Name"]).startswith(("
 idx = starts[-1 - back]
 t0 = int(rows[idx]["Start_Timestamp"])
 print("\nframe launch sequence (start offset us, duration us, grid):")
-for r in rows[idx:]:
+for n, r in enumerate(rows[idx:]):
     k = short(r["Kernel_Name"])
+    if n > 0 and (not k.startswith("k_") or k.startswith(("k_trace<true", "k_level<true", "k_bvh_trace<true"))):
+        break      # the frame's kernels are over (a copy, or the next frame's first kernel)
     print(f"  {(int(r['Start_Timestamp'])-t0)/1e3:9.1f} {(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3:9.1f}  {k:24s} {r['Grid_Size_X']}")
-    if k.startswith("k_finish"):
-        break
