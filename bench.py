@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--workload", default="cornell_1080p_b4")
     ap.add_argument("--partition", default="interleaved", choices=["interleaved", "bands"])
     ap.add_argument("--accel", default="auto", choices=["auto", "brute", "lbvh"], help="closest-hit structure (auto: by scene size)")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="independent frames traced at the same time, each with a context and a stream of its own "
+                         "(0: two for brute-force scenes, one for LBVH scenes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-row-step", type=int, default=0, help="CPU baseline renders every n-th row (0: every row for the headline workload, one row per thread otherwise)")
     args = ap.parse_args()
@@ -114,22 +117,34 @@ def main():
 
     flat, options = get_flat_workload(args.workload)
     seed = 0
-    ctx = _native.Context(local_rank)
-    ctx.set_accel(args.accel)
-    ctx.upload(flat)
+    # Consecutive frames are independent, and the launches of one 1080p frame are too small to keep the device full
+    # through their starts and ends: F frames are in flight, each a chain of its own (context, stream, tile buffer;
+    # trace, then gather, on that stream) with nothing that orders one chain against another.  Every step is still one
+    # complete frame, traced and gathered.
+    lbvh_scene = args.accel == "lbvh" or (args.accel == "auto" and flat.n_tris + flat.n_spheres > 256)
+    F = args.frames_in_flight if args.frames_in_flight > 0 else (1 if lbvh_scene else 2)
     H, W = options["height"], options["width"]
     tile = partition_rows(H, world, rank, args.partition)
-    out = torch.empty((tile.nrows, W, 3), dtype=torch.uint8, device=device)
-    # an explicit stream: a null handle would mean "the context's own stream" to the library, and the gather that
-    # follows every render on torch's current stream has to be ordered behind it
-    torch_stream = torch.cuda.Stream(device)
-    torch.cuda.set_stream(torch_stream)
-    stream = torch_stream.cuda_stream
+    ctxs, outs, streams = [], [], []
+    for _ in range(F):
+        c = _native.Context(local_rank)
+        c.set_accel(args.accel)
+        c.upload(flat)
+        ctxs.append(c)
+        outs.append(torch.empty((tile.nrows, W, 3), dtype=torch.uint8, device=device))
+        # explicit streams: a null handle would mean "the context's own stream" to the library, and the gather that
+        # follows every render has to be ordered behind it
+        streams.append(torch.cuda.Stream(device))
+    ctx = ctxs[0]
+    counter = [0]
 
     def step(want_stats):
-        st = ctx.render_rows_device(options, seed, tile.row0, tile.nrows, out.data_ptr(), stream=stream,
-                                    want_stats=want_stats, row_stride=tile.stride)
-        frame = gather_frame(out, H, args.partition)
+        k = counter[0] % F
+        counter[0] += 1
+        torch.cuda.set_stream(streams[k])
+        st = ctxs[k].render_rows_device(options, seed, tile.row0, tile.nrows, outs[k].data_ptr(), stream=streams[k].cuda_stream,
+                                        want_stats=want_stats, row_stride=tile.stride)
+        frame = gather_frame(outs[k], H, args.partition)
         return st, frame
 
     def sync():
@@ -142,16 +157,21 @@ def main():
     for _ in range(max(0, args.warmup - 1)):
         step(False)
     sync()
+    for c in ctxs:
+        c.set_timing(False)
     t0 = time.perf_counter()
-    # per-kernel events (a few us of stream idle time each) are recorded in the last timed step only
-    ctx.set_timing(False)
     for i in range(args.steps):
-        if i == args.steps - 1:
-            ctx.set_timing(True)
         step(False)
     sync()
     elapsed = time.perf_counter() - t0
-    last = ctx.last_call_stats()  # kernel durations of the last timed step (HIP events on the launch stream)
+    # kernel durations (HIP events on the launch stream) come from one more frame, outside the timed region and alone
+    # on the device: events between the launches are stops in the stream, and kernels that share the device with
+    # another frame's have no duration of their own
+    ctx.set_timing(True)
+    torch.cuda.set_stream(streams[0])
+    last = ctx.render_rows_device(options, seed, tile.row0, tile.nrows, outs[0].data_ptr(), stream=streams[0].cuda_stream,
+                                  want_stats=True, row_stride=tile.stride)
+    sync()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
@@ -178,6 +198,7 @@ def main():
             "config": {"workload": args.workload, "width": W, "height": H, "bounces": options["bounces"],
                        "samples": options["samples"], "triangles": T, "spheres_and_lights": S,
                        "lights": int(len(flat.light_strength)), "partition": f"{args.partition} rows x{world}",
+                       "frames_in_flight": F,
                        "queries_per_frame": totals["queries"], "rendered_rays_per_frame": totals["rays_api"]},
             "roofline": {"bound": "valu", "kernel": "k_level", "achieved": round(achieved, 3), "peak": FP32_VALU_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4), "traffic": None,
@@ -185,7 +206,12 @@ def main():
                          "avg_launch_ms": round(last["ms_k_level"] / max(1, last["n_k_level"]), 5),
                          "flops_per_launch": flops / max(1, last["n_k_level"]),
                          "queries_per_launch": last["queries"] / max(1, last["n_k_level"]),
-                         "frame_device_ms": round(last["ms_device"], 4), "resolve_ms": round(last["ms_resolve"], 4)},
+                         "frame_device_ms": round(last["ms_device"], 4), "resolve_ms": round(last["ms_resolve"], 4),
+                         "measured_on": "one frame alone on the device, after the timed steps"},
+            # the whole pipeline as timed: every flop of the frame over the time a frame takes with F in flight
+            "pipeline": {"frames_in_flight": F, "frame_latency_ms": round(last["ms_device"], 4),
+                         "achieved": round(flops / (ms_per_step * 1e-3) / 1e12, 3), "unit": "TFLOP/s",
+                         "frac": round(flops / (ms_per_step * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 4)},
         }
         tr = pmc_traffic(args.workload) if world == 1 else None
         if tr:

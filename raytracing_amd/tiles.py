@@ -58,7 +58,7 @@ def assemble(tiles, height: int, mode: str = "interleaved"):
     return frame
 
 
-_workspace = {}   # receive buffer and frame of the last gather shape (rank dst only)
+_workspace = {}   # receive buffer and frame per gather shape and stream (rank dst only)
 
 
 def gather_frame(tile, height: int, mode: str = "interleaved", group=None, dst: int = 0):
@@ -75,10 +75,16 @@ def gather_frame(tile, height: int, mode: str = "interleaved", group=None, dst: 
     if rank == dst:
         # one receive buffer [G, H/G, W, C] and one frame, kept between calls; the tiles land in the buffer
         # and a single strided copy puts the rows in place
-        key = (tuple(tile.shape), tile.dtype, tile.device, world, height)
+        # per stream: two frames in flight on two streams must not share a receive buffer
+        stream_id = 0
+        if tile.is_cuda:
+            import torch
+            stream_id = torch.cuda.current_stream(tile.device).cuda_stream
+        key = (tuple(tile.shape), tile.dtype, tile.device, world, height, stream_id)
         ws = _workspace.get(key)
         if ws is None:
-            _workspace.clear()
+            if len(_workspace) > 8:
+                _workspace.clear()
             ws = (tile.new_empty((world,) + tuple(tile.shape)), tile.new_empty((height,) + tuple(tile.shape[1:])))
             _workspace[key] = ws
         stacked, frame = ws

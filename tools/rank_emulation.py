@@ -1,5 +1,6 @@
 """What one rank of an N-GPU run does per frame, timed on one GPU: rows r, r+N, ... of the benchmark frame
-(no gather); usage: rank_emulation.py [workload] [N ...].  Shows the fixed per-frame cost that limits strong scaling."""
+(no gather); usage: rank_emulation.py [workload] [fF] [N ...]; fF: F frames in flight, each with a context and a
+stream of its own (default f1).  Shows the fixed per-frame cost that limits strong scaling."""
 import sys, time
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,10 +9,17 @@ from raytracing_amd import _native
 from raytracing_amd.workloads import get_flat_workload
 args = sys.argv[1:]
 workload = "cornell_1080p_b4"
-if args and not args[0].isdigit():
+if args and not args[0].isdigit() and not (args[0][0] == "f" and args[0][1:].isdigit()):
     workload = args.pop(0)
+F = 1
+if args and args[0].startswith("f"):
+    F = int(args.pop(0)[1:])
 flat, opt = get_flat_workload(workload)
 ctx = _native.Context(0); ctx.upload(flat)
+more = [_native.Context(0) for _ in range(F - 1)]
+for c in more:
+    c.upload(flat); c.set_timing(False)
+more_streams = [torch.cuda.Stream(torch.device("cuda", 0)) for _ in range(F - 1)]
 H, W = opt["height"], opt["width"]
 dev = torch.device("cuda", 0)
 torch_stream = torch.cuda.Stream(dev)
@@ -25,14 +33,19 @@ for n in ([int(a) for a in args] or [1, 2, 4, 8]):
     for _ in range(3):
         ctx.render_rows_device(opt, 0, 0, rows, out.data_ptr(), stream=stream, want_stats=False, row_stride=n)
     torch.cuda.synchronize()
+    chains = [(ctx, stream, out)] + [(c, s.cuda_stream, torch.empty_like(out)) for c, s in zip(more, more_streams)]
+    K = 60 if workload == "cornell_1080p_b4" else 6
+    for i in range(F):
+        chains[i][0].render_rows_device(opt, 0, 0, rows, chains[i][2].data_ptr(), stream=chains[i][1], want_stats=False, row_stride=n)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    K = 50 if workload == "cornell_1080p_b4" else 5
-    for _ in range(K):
-        ctx.render_rows_device(opt, 0, 0, rows, out.data_ptr(), stream=stream, want_stats=False, row_stride=n)
+    for i in range(K):
+        c, s_, o_ = chains[i % F]
+        c.render_rows_device(opt, 0, 0, rows, o_.data_ptr(), stream=s_, want_stats=False, row_stride=n)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / K * 1e3
     ctx.set_timing(True)
     print(f"ranks {n}: rows {rows}  {ms:.4f} ms/frame per rank  queries {st['queries']}  -> speedup bound {0:.2f}" if n == 1 else
-          f"ranks {n}: rows {rows}  {ms:.4f} ms/frame per rank  queries {st['queries']}")
+          f"ranks {n}: rows {rows}  {ms:.4f} ms/frame per rank ({F} in flight)  queries {st['queries']}")
     print("   k_level ms per level", [round(x, 4) for x in st["level_ms"][:opt["bounces"] + 1]], "resolve+finish ms", round(st["ms_resolve"], 4),
           "rays per level", st["level_rays"][:opt["bounces"] + 1], "nodes", st["level_nodes"][:opt["bounces"] + 1])
