@@ -1325,6 +1325,15 @@ struct t3d_ctx {
     bool last_events = true;   // the band recorded its start and end
     bool last_valid = false; int last_levels = 0; size_t last_n0 = 0; int last_lights = 1; uint64_t last_launches = 0;
     hipStream_t last_stream = nullptr;
+    // Launch graphs of repeated asynchronous bands: the same band (same options, rows, buffers, scene) asked for again
+    // is one graph launch instead of ten kernel launches (0.1 ms of host time per call otherwise).
+    struct FrameGraph { bool valid = false; char key[320] = {}; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; uint64_t launches = 0; };
+    FrameGraph graphs[4];
+    int graph_next = 0;
+    char graph_miss[2][320] = {};   // bands that were launched kernel by kernel most recently: a graph is made at the second request
+    int graph_miss_next = 0;
+    bool graphs_enabled = true;
+    uint64_t scene_gen = 0;         // counts uploads
     bool counters_on_host = false;   // h_cnt holds (or is about to receive) the counters of the most recent band
 };
 
@@ -1369,6 +1378,7 @@ extern "C" int t3d_create(int device, t3d_ctx** out) {
     hipStreamCreateWithFlags(&c->shadow_stream, hipStreamNonBlocking);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_sm = prop.multiProcessorCount;
+    if (getenv("T3D_NO_GRAPHS")) c->graphs_enabled = false;
     if (hipMalloc((void**)&c->d_cnt_pair[0], sizeof(Counters)) != hipSuccess || hipMalloc((void**)&c->d_cnt_pair[1], sizeof(Counters)) != hipSuccess ||
         hipMemset(c->d_cnt_pair[0], 0, sizeof(Counters)) != hipSuccess || hipMemset(c->d_cnt_pair[1], 0, sizeof(Counters)) != hipSuccess ||
         hipMalloc((void**)&c->d_fetch, sizeof(PaddedCount) * (T3D_MAX_BOUNCES + 2) * 2 * T3D_SHARDS) != hipSuccess ||
@@ -1405,6 +1415,7 @@ extern "C" void t3d_destroy(t3d_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     free_scene(c); free_work(c);
     hipFree(c->d_sample_color); hipFree(c->d_cnt_pair[0]); hipFree(c->d_cnt_pair[1]); hipFree(c->d_fetch); hipHostFree(c->h_cnt);
+    for (auto& g : c->graphs) if (g.valid) { hipGraphExecDestroy(g.exec); hipGraphDestroy(g.graph); }
     hipFree(c->d_bgr); hipFree(c->d_rad); hipFree(c->d_prim); hipFree(c->d_prim_t);
     if (c->h_stage) hipHostFree(c->h_stage);
     for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
@@ -1671,6 +1682,7 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
     d.cam.zlen = (float)s->cam_zlen;
     c->n_objects = s->n_objects;
     c->has_scene = true;
+    c->scene_gen++;
     return T3D_OK;
 }
 
@@ -1837,6 +1849,32 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
     const bool overlap = c->use_bvh && !c->timing && !single;
     // a call that stays asynchronous and is not being timed gets no events at all: each one is a stop in the stream
     const bool events = c->timing || stats || single;
+    // ---- launch graph of a repeated band (brute-force path, nothing but kernels in the stream) ----
+    char key[sizeof c->graphs[0].key];
+    static_assert(sizeof(RenderParams) + 12 * sizeof(void*) <= sizeof key, "graph key");
+    const bool graphable = c->graphs_enabled && !events && !single && !c->use_bvh;
+    bool capturing = false;
+    t3d_ctx::FrameGraph* slot = nullptr;
+    if (graphable) {
+        memset(key, 0, sizeof key);
+        memcpy(key, &rp, sizeof rp);
+        const void* ptrs[12] = {d_bgr, d_rad, d_prim, d_prim_t, c->d_cnt, next_cnt, c->d_rays[0], c->d_rays[1], c->pool.c, c->pool.li,
+                                c->d_sample_color, (const void*)(uintptr_t)c->scene_gen};
+        memcpy(key + sizeof rp, ptrs, sizeof ptrs);
+        for (auto& g : c->graphs)
+            if (g.valid && memcmp(g.key, key, sizeof key) == 0) {
+                HIPCHK(c, hipGraphLaunch(g.exec, st));
+                launches = g.launches;
+                goto issued;
+            }
+        if (memcmp(c->graph_miss[0], key, sizeof key) == 0 || memcmp(c->graph_miss[1], key, sizeof key) == 0) {
+            if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess) capturing = true;
+            else { (void)hipGetLastError(); c->graphs_enabled = false; }
+        } else {
+            memcpy(c->graph_miss[c->graph_miss_next], key, sizeof key);
+            c->graph_miss_next ^= 1;
+        }
+    }
     if (events) HIPCHK(c, tick());  // ev[0]: start of the call
     for (int d = 0; d < levels; ++d) {
         RayRec* in = c->d_rays[d & 1];
@@ -1895,6 +1933,27 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
         hipLaunchKernelGGL(k_finish, dim3(blocks_for((size_t)nrows * o->width)), dim3(T3D_BLOCK), 0, st, rp, c->d_sample_color, d_bgr, d_rad);
         launches++;
     }
+    if (capturing) {
+        // what was queued above was recorded, not run: make the graph, keep it, run it
+        slot = &c->graphs[c->graph_next];
+        c->graph_next = (c->graph_next + 1) % 4;
+        if (slot->valid) { hipGraphExecDestroy(slot->exec); hipGraphDestroy(slot->graph); slot->valid = false; }
+        hipError_t e = hipStreamEndCapture(st, &slot->graph);
+        if (e == hipSuccess) {
+            e = hipGraphInstantiate(&slot->exec, slot->graph, nullptr, nullptr, 0);
+            if (e != hipSuccess) hipGraphDestroy(slot->graph);
+        }
+        if (e != hipSuccess) {
+            c->graphs_enabled = false;   // this band is lost; the caller may simply ask again, kernels are launched one by one from now on
+            c->err = std::string("launch graph: ") + hipGetErrorString(e);
+            return T3D_E_DEVICE;
+        }
+        memcpy(slot->key, key, sizeof key);
+        slot->launches = launches;
+        slot->valid = true;
+        HIPCHK(c, hipGraphLaunch(slot->exec, st));
+    }
+issued:
     c->cnt_clean = true;
     if (events) HIPCHK(c, tick());  // last event: end of the call
     HIPCHK(c, hipGetLastError());
