@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--accel", default="auto", choices=["auto", "brute", "lbvh"], help="closest-hit structure (auto: by scene size)")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="independent frames traced at the same time, each with a context and a stream of its own "
-                         "(0: two for brute-force scenes, one for LBVH scenes)")
+                         "(0: one for LBVH scenes; brute-force scenes two with one rank, three with two, four with more)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-row-step", type=int, default=0, help="CPU baseline renders every n-th row (0: every row for the headline workload, one row per thread otherwise)")
     args = ap.parse_args()
@@ -122,13 +122,16 @@ def main():
     # trace, then gather, on that stream) with nothing that orders one chain against another.  Every step is still one
     # complete frame, traced and gathered.
     lbvh_scene = args.accel == "lbvh" or (args.accel == "auto" and flat.n_tris + flat.n_spheres > 256)
-    F = args.frames_in_flight if args.frames_in_flight > 0 else (1 if lbvh_scene else 2)
+    # one rank's share of a frame is a chain of small launches: more of them in flight, and full rounds (no slot of a
+    # round wasted; the other chains hide the latency the adaptive cut is there to shorten)
+    F = args.frames_in_flight if args.frames_in_flight > 0 else (1 if lbvh_scene else (2 if world == 1 else (3 if world == 2 else 4)))
     H, W = options["height"], options["width"]
     tile = partition_rows(H, world, rank, args.partition)
     ctxs, outs, streams = [], [], []
     for _ in range(F):
         c = _native.Context(local_rank)
         c.set_accel(args.accel)
+        c.set_full_rounds(F >= 3)
         c.upload(flat)
         ctxs.append(c)
         outs.append(torch.empty((tile.nrows, W, 3), dtype=torch.uint8, device=device))

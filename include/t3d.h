@@ -221,6 +221,16 @@ int t3d_last_call_stats(t3d_ctx* ctx, t3d_stats* stats);
 int t3d_set_timing(t3d_ctx* ctx, int per_kernel);
 
 /*
+ * How a launch with little work (a thin band, one rank's share of a frame) is cut up.  ADAPTIVE (default): into
+ * more, smaller trace rounds, so that more waves share it: shortest time for one band alone on the device.
+ * FULL: always 128 rays per round, no slot wasted: highest throughput when the caller keeps several bands in
+ * flight (several contexts on several streams), which hide each other's latency.  Same pixels either way.
+ * No counterpart in the reference.
+ */
+enum { T3D_ROUNDS_ADAPTIVE = 0, T3D_ROUNDS_FULL = 1 };
+int t3d_set_rounds(t3d_ctx* ctx, int mode);
+
+/*
  * Acceleration structure used by scenes uploaded AFTER this call.
  *   T3D_ACCEL_AUTO         brute force over plane groups up to T3D_BRUTE_FORCE_MAX_PRIMS triangles + spheres,
  *                          the LBVH above (default)

@@ -16,7 +16,7 @@ ABI_VERSION = 2
 
 SYMBOLS = ("t3d_abi_version", "t3d_device_count", "t3d_create", "t3d_destroy", "t3d_last_error",
            "t3d_upload_scene", "t3d_render_rows", "t3d_render_rows_device", "t3d_trace_pixel", "t3d_trace_ray",
-           "t3d_closest_hits", "t3d_last_call_stats", "t3d_set_timing", "t3d_set_accel")
+           "t3d_closest_hits", "t3d_last_call_stats", "t3d_set_timing", "t3d_set_accel", "t3d_set_rounds")
 
 
 class NativeError(RuntimeError):
@@ -95,6 +95,8 @@ def load():
     lib.t3d_last_call_stats.argtypes = [C.c_void_p, P(Stats)]
     lib.t3d_set_timing.restype = C.c_int
     lib.t3d_set_timing.argtypes = [C.c_void_p, C.c_int]
+    lib.t3d_set_rounds.restype = C.c_int
+    lib.t3d_set_rounds.argtypes = [C.c_void_p, C.c_int]
     lib.t3d_set_accel.restype = C.c_int
     lib.t3d_set_accel.argtypes = [C.c_void_p, C.c_int]
     if lib.t3d_abi_version() != ABI_VERSION:
@@ -188,6 +190,10 @@ class Context:
         """'auto' | 'brute' | 'lbvh' for scenes uploaded after this call."""
         code = {"auto": 0, "brute": 1, "lbvh": 2}[mode]
         self._check(self._lib.t3d_set_accel(self._h, code), "t3d_set_accel")
+
+    def set_full_rounds(self, full: bool):
+        """Always 128 rays per trace round (for callers that keep several bands in flight) instead of the adaptive cut."""
+        self._check(self._lib.t3d_set_rounds(self._h, 1 if full else 0), "t3d_set_rounds")
 
     def set_timing(self, per_kernel: bool):
         """Per-kernel event timing on/off (on: ms_k_level / ms_resolve filled, a few us of idle per launch)."""

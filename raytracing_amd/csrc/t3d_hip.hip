@@ -129,6 +129,7 @@ struct RenderParams {
     int want_debug;  // record t3d_node entries (t3d_trace_pixel)
     int px0, py0, sample0;  // single-sample mode (t3d_trace_pixel / t3d_trace_ray): key of the random numbers
     int single;             // 0 image band, 1 one pixel sample (camera ray), 2 one explicit ray
+    int full_rounds;        // always 128 rays per trace round (t3d_set_rounds)
     int tiled;              // level 0 walks the band in 16 x 8 pixel tiles (width % 16 == 0, rows % 8 == 0)
     float ray_o[3], ray_d[3], ray_ior;  // single == 2: the initial ray (unit direction) ...
     int ray_obj;                        // ... and the object it travels inside (-1 none)
@@ -941,10 +942,11 @@ __global__ __launch_bounds__(T3D_BLOCK, 4) void k_level(DevScene sc, GEO_PARAMS,
     // Rays per trace round.  A launch with little work (a thin band of rows, one rank's share of a frame) is
     // bound by the number of rounds one wave runs back to back -- a trace round and the shadow rounds of the
     // nodes it creates -- not by throughput: such a launch is cut into more, smaller chunks (64 or 32 rays,
-    // one per lane) as long as every chunk still finds a resident wave.
+    // one per lane) as long as every chunk still finds a resident wave.  A caller that keeps several bands in flight on
+    // several contexts hides that latency itself and asks for full rounds, which waste no slots (t3d_set_rounds).
     const int resident_all = nw < rp.resident_waves ? nw : rp.resident_waves;
     const int resident = LEVEL0 ? resident_all : resident_all / T3D_SHARDS;
-    const int cs = n_in > 64 * resident ? 128 : (n_in > 32 * resident ? 64 : 32);
+    const int cs = rp.full_rounds || n_in > 64 * resident ? 128 : (n_in > 32 * resident ? 64 : 32);
     int ring_nodes = 0;  // nodes appended to the ring so far      (wave-uniform)
     int items_done = 0;  // (node, light) pairs already traced     (wave-uniform)
     const float inv_L = 1.0f / (float)(L > 0 ? L : 1);
@@ -1333,6 +1335,7 @@ struct t3d_ctx {
     char graph_miss[2][320] = {};   // bands that were launched kernel by kernel most recently: a graph is made at the second request
     int graph_miss_next = 0;
     bool graphs_enabled = true;
+    bool full_rounds = false;       // t3d_set_rounds
     uint64_t scene_gen = 0;         // counts uploads
     bool counters_on_host = false;   // h_cnt holds (or is about to receive) the counters of the most recent band
 };
@@ -1804,6 +1807,7 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
     rp.n0 = (int)n0;
     rp.resident_waves = c->n_sm * 16;   // 4 waves per SIMD at this kernel's register count
     rp.tiled = !single && o->width % 16 == 0 && nrows % 8 == 0;
+    rp.full_rounds = c->full_rounds && !single;
     if (single) {
         rp.single = single->single; rp.px0 = single->px0; rp.py0 = single->py0; rp.sample0 = single->sample0; rp.want_debug = 1;
         for (int k = 0; k < 3; ++k) { rp.ray_o[k] = single->ray_o[k]; rp.ray_d[k] = single->ray_d[k]; }
@@ -2031,6 +2035,13 @@ extern "C" int t3d_set_accel(t3d_ctx* c, int mode) {
     if (!c) return T3D_E_INVALID;
     if (mode != T3D_ACCEL_AUTO && mode != T3D_ACCEL_BRUTE_FORCE && mode != T3D_ACCEL_LBVH) { c->err = "t3d_set_accel: unknown mode"; return T3D_E_INVALID; }
     c->accel = mode;
+    return T3D_OK;
+}
+
+extern "C" int t3d_set_rounds(t3d_ctx* c, int mode) {
+    if (!c) return T3D_E_INVALID;
+    if (mode != T3D_ROUNDS_ADAPTIVE && mode != T3D_ROUNDS_FULL) { c->err = "t3d_set_rounds: unknown mode"; return T3D_E_INVALID; }
+    c->full_rounds = mode == T3D_ROUNDS_FULL;
     return T3D_OK;
 }
 

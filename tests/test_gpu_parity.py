@@ -439,3 +439,20 @@ def test_device_outputs_follow_the_callers_stream(gpu_ctx):
             assert np.array_equal(host["bgr"], got_bgr) and np.array_equal(host["radiance"], got_rad)
         assert not np.array_equal(frames[0][0], frames[1][0])          # the seeds do differ
         assert st["rays_api"] == host["stats"]["rays_api"] and st["queries"] == host["stats"]["queries"]
+
+
+def test_full_rounds_give_the_same_picture(gpu_ctx):
+    """t3d_set_rounds: a thin band cut into full 128-ray rounds or adaptively is the same picture and the same counts."""
+    flat = flat_for("config2_cornell_light.json")
+    gpu_ctx.set_accel("auto")
+    gpu_ctx.upload(flat)
+    opt = dict(width=160, height=120, bounces=3, samples=2)
+    got = {}
+    for full in (False, True):
+        gpu_ctx.set_full_rounds(full)
+        got[full] = gpu_ctx.render_rows(opt, seed=6, row0=3, nrows=15, row_stride=8, want_radiance=True, want_primary=True)
+    gpu_ctx.set_full_rounds(False)
+    a, b = got[False], got[True]
+    assert np.array_equal(a["bgr"], b["bgr"]) and np.array_equal(a["prim"], b["prim"]) and np.array_equal(a["radiance"], b["radiance"])
+    for key in ("rays_api", "queries", "nodes"):
+        assert a["stats"][key] == b["stats"][key], key

@@ -17,6 +17,8 @@ if args and args[0].startswith("f"):
 flat, opt = get_flat_workload(workload)
 ctx = _native.Context(0); ctx.upload(flat)
 more = [_native.Context(0) for _ in range(F - 1)]
+for c in [ctx] + more:
+    c.set_full_rounds(F >= 3)
 for c in more:
     c.upload(flat); c.set_timing(False)
 more_streams = [torch.cuda.Stream(torch.device("cuda", 0)) for _ in range(F - 1)]
