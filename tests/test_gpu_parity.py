@@ -456,3 +456,56 @@ def test_full_rounds_give_the_same_picture(gpu_ctx):
     assert np.array_equal(a["bgr"], b["bgr"]) and np.array_equal(a["prim"], b["prim"]) and np.array_equal(a["radiance"], b["radiance"])
     for key in ("rays_api", "queries", "nodes"):
         assert a["stats"][key] == b["stats"][key], key
+
+
+def test_replayed_bands_match_fresh_ones(gpu_ctx):
+    """A band asked for again and again is replayed as a launch graph from the third request on: same pixels as the
+    first time, no stale replay once the seed, the rows or the scene change, and the counters stay right."""
+    import torch
+    from raytracing_amd.scene import Scene
+    from raytracing_amd.flatten import flatten_scene
+    import os
+    from conftest import SCENES
+    flat = flat_for("config2_cornell_light.json")
+    gpu_ctx.set_accel("auto")
+    gpu_ctx.upload(flat)
+    opt = dict(width=160, height=96, bounces=3, samples=1)
+    dev = torch.device("cuda", 0)
+    torch_stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(torch_stream)
+    stream = torch_stream.cuda_stream
+    gpu_ctx.set_timing(False)
+    bgr = torch.zeros((96, 160, 3), dtype=torch.uint8, device=dev)
+
+    def device_frame(seed, nrows=96):
+        bgr.zero_()
+        gpu_ctx.render_rows_device(opt, seed, 0, nrows, bgr.data_ptr(), stream=stream, want_stats=False)
+        return bgr.clone()
+
+    frames = [device_frame(1) for _ in range(8)]          # both counter sets get their graph on the way
+    st = gpu_ctx.last_call_stats()
+    other = device_frame(2)
+    again = [device_frame(1) for _ in range(3)]
+    half = device_frame(1, nrows=48)
+    torch.cuda.synchronize()
+    gpu_ctx.set_timing(True)
+    want1 = gpu_ctx.render_rows(opt, seed=1)
+    want2 = gpu_ctx.render_rows(opt, seed=2)
+    for f in frames + again:
+        assert np.array_equal(f.cpu().numpy(), want1["bgr"])
+    assert np.array_equal(other.cpu().numpy(), want2["bgr"]) and not np.array_equal(want1["bgr"], want2["bgr"])
+    h = half.cpu().numpy()
+    assert np.array_equal(h[:48], want1["bgr"][:48]) and (h[48:] == 0).all()
+    assert st["queries"] == want1["stats"]["queries"] and st["rays_api"] == want1["stats"]["rays_api"]
+    # another scene in the same buffers: the graphs of the old one must not be replayed
+    scene = Scene.fromJSON(os.path.join(SCENES, "config2_cornell_light.json"))
+    scene.objects = [o for o in scene.objects if o.type != "sphere"]
+    gpu_ctx.upload(flatten_scene(scene))
+    gpu_ctx.set_timing(False)
+    changed = [device_frame(1) for _ in range(4)]
+    torch.cuda.synchronize()
+    gpu_ctx.set_timing(True)
+    want3 = gpu_ctx.render_rows(opt, seed=1)
+    assert not np.array_equal(want3["bgr"], want1["bgr"])
+    for f in changed:
+        assert np.array_equal(f.cpu().numpy(), want3["bgr"])
