@@ -8,13 +8,17 @@
 
 One step = one complete frame: every rank traces its interleaved image rows through libt3d_hip.so
 (scene resident in HBM, output tile in HBM), then the tiles are gathered on rank 0 (RCCL).  A "ray" is
-one closest-hit query (primary + bounce + transmit + shadow).  Prints ONE JSON line on rank 0.
+one closest-hit query (primary + bounce + transmit + shadow).  Consecutive steps are independent frames, and
+several are in flight at a time (--frames-in-flight, config.frames_in_flight), each a chain of its own: a
+context, a stream, a tile buffer; trace, then gather, on that stream.  Prints ONE JSON line on rank 0.
 
 The line also carries
   roofline      FP32 vector-ALU roofline of the dominant kernel (k_level, which runs every closest-hit
                 query of a tree level): algorithmic flops (51 per ray-triangle test, 19 per ray-sphere
-                test) divided by the kernel's launch durations, measured with HIP events in the last
-                timed step
+                test) divided by the kernel's launch durations, measured with HIP events on one more
+                frame after the timed steps, alone on the device
+  pipeline      the same flops over the time a step takes with the frames in flight, and the latency of
+                one frame alone
   cpu_baseline  the float64 CPU oracle (oracle/, a restatement of the reference's algorithm) timed on this
                 host's cores on a bounded sample of the same frame (N = 1 only)
 """
