@@ -85,17 +85,21 @@ def gather_frame(tile, height: int, mode: str = "interleaved", group=None, dst: 
         if ws is None:
             if len(_workspace) > 8:
                 _workspace.clear()
-            ws = (tile.new_empty((world,) + tuple(tile.shape)), tile.new_empty((height,) + tuple(tile.shape[1:])))
+            stacked = tile.new_empty((world,) + tuple(tile.shape))
+            frame = tile.new_empty((height,) + tuple(tile.shape[1:]))
+            n = height // world
+            if mode == "bands":
+                dst_view, src_view = frame.view((world, n) + tuple(tile.shape[1:])), stacked
+            elif mode == "interleaved":
+                dst_view, src_view = frame.view((n, world) + tuple(tile.shape[1:])), stacked.transpose(0, 1)
+            else:
+                raise ValueError(f"unknown partition mode {mode!r}")
+            # the per-rank views and the two sides of the copy are made once: this runs every frame
+            ws = ([stacked[r] for r in range(world)], frame, dst_view, src_view)
             _workspace[key] = ws
-        stacked, frame = ws
-        dist.gather(tile, [stacked[r] for r in range(world)], dst=dst, group=group)
-        n = height // world
-        if mode == "bands":
-            frame.view((world, n) + tuple(tile.shape[1:])).copy_(stacked)
-        elif mode == "interleaved":
-            frame.view((n, world) + tuple(tile.shape[1:])).copy_(stacked.transpose(0, 1))
-        else:
-            raise ValueError(f"unknown partition mode {mode!r}")
+        parts, frame, dst_view, src_view = ws
+        dist.gather(tile, parts, dst=dst, group=group)
+        dst_view.copy_(src_view)
         return frame
     dist.gather(tile, None, dst=dst, group=group)
     return None
