@@ -18,7 +18,9 @@
 //   for depth d = bounces .. 0:
 //       k_resolve one thread per node: computeColor (T3DR.py:1004-1083) from the two child slots
 //                 and the direct light, pushes the colour into the parent's slot
-//   k_finish      per pixel: mean over samples, floor, clamp, BGR8 store (T3DR.py:1219-1221)
+//   k_finish      per pixel: mean over samples, floor, clamp, BGR8 store (T3DR.py:1219-1221); with one sample
+//                 per pixel the kernel that finishes the sample (k_level at a leaf, k_resolve at level 0)
+//                 stores the pixel itself and k_finish is not launched
 //
 // The colour of a node is a clamped (non-linear) function of its children, so the tree is kept in
 // HBM and resolved bottom-up; a throughput-accumulating path tracer would not give the same image.
@@ -1814,7 +1816,7 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
         rp.ray_ior = single->ray_ior; rp.ray_obj = single->ray_obj;
     }
 
-    static_assert(sizeof(Counters) % sizeof(uint4) == 0, "k_finish clears the counters in 16-byte pieces");
+    static_assert(sizeof(Counters) % sizeof(uint4) == 0, "k_resolve clears the counters in 16-byte pieces");
     c->d_cnt = c->d_cnt_pair[c->cnt_idx];               // all zero: cleared by the band before (or at creation) ...
     if (!c->cnt_clean) HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), st));   // ... unless that band was cut short
     Counters* next_cnt = c->d_cnt_pair[c->cnt_idx ^ 1];
