@@ -173,6 +173,12 @@ def main():
         step(False)
     sync()
     elapsed = time.perf_counter() - t0
+    # the timed calls were asynchronous and checked nothing: every chain's last frame must have fitted its buffers
+    # and counted the same queries as the checked first step (raises on a capacity overflow)
+    for c in ctxs:
+        chain_stats = c.last_call_stats()
+        if chain_stats["queries"] != first_stats["queries"]:
+            raise RuntimeError(f"a timed frame traced {chain_stats['queries']} queries, the checked frame {first_stats['queries']}")
     # kernel durations (HIP events on the launch stream) come from one more frame, outside the timed region and alone
     # on the device: events between the launches are stops in the stream, and kernels that share the device with
     # another frame's have no duration of their own
@@ -181,6 +187,11 @@ def main():
     last = ctx.render_rows_device(options, seed, tile.row0, tile.nrows, outs[0].data_ptr(), stream=streams[0].cuda_stream,
                                   want_stats=True, row_stride=tile.stride)
     sync()
+    # every chain rendered the same frame: the tiles left by the timed, replayed, concurrent calls must equal the
+    # tile of the call just made alone
+    for k in range(1, F):
+        if not torch.equal(outs[k], outs[0]):
+            raise RuntimeError(f"the tile of chain {k} differs from the tile rendered alone")
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
