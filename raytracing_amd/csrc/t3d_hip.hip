@@ -1339,6 +1339,7 @@ struct t3d_ctx {
     bool graphs_enabled = true;
     bool full_rounds = false;       // t3d_set_rounds
     uint64_t scene_gen = 0;         // counts uploads
+    uint64_t work_gen = 0;          // counts (re)allocations of the work buffers: a graph holds their addresses
     bool counters_on_host = false;   // h_cnt holds (or is about to receive) the counters of the most recent band
 };
 
@@ -1406,6 +1407,7 @@ static void free_scene(t3d_ctx* c) {
     c->has_scene = false;
 }
 static void free_work(t3d_ctx* c) {
+    c->work_gen++;
     hipFree(c->d_rays[0]); hipFree(c->d_rays[1]); hipFree(c->pool.parent); hipFree(c->pool.c);
     hipFree(c->pool.d); hipFree(c->pool.dbg); hipFree(c->pool.li);
     hipFree(c->d_hits);
@@ -1715,6 +1717,7 @@ static int ensure_work(t3d_ctx* c, size_t cap, int levels, size_t n0, bool dbg) 
     }
     if (n0 > c->n0_alloc) {
         hipFree(c->d_sample_color); c->d_sample_color = nullptr; c->n0_alloc = 0;
+        c->work_gen++;
         HIPCHK(c, hipMalloc((void**)&c->d_sample_color, sizeof(float4) * n0));
         c->n0_alloc = n0;
     }
@@ -1865,7 +1868,7 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
         memset(key, 0, sizeof key);
         memcpy(key, &rp, sizeof rp);
         const void* ptrs[12] = {d_bgr, d_rad, d_prim, d_prim_t, c->d_cnt, next_cnt, c->d_rays[0], c->d_rays[1], c->pool.c, c->pool.li,
-                                c->d_sample_color, (const void*)(uintptr_t)c->scene_gen};
+                                c->d_sample_color, (const void*)(uintptr_t)((c->scene_gen << 32) ^ c->work_gen)};
         memcpy(key + sizeof rp, ptrs, sizeof ptrs);
         for (auto& g : c->graphs)
             if (g.valid && memcmp(g.key, key, sizeof key) == 0) {
