@@ -154,12 +154,18 @@ class Context:
         self.flat = flat
 
     def render_rows(self, options: dict, seed: int = 0, row0: int = 0, nrows: int | None = None,
-                    want_radiance=False, want_primary=False, row_stride: int = 1):
-        """-> dict(bgr uint8 [rows,W,3], radiance, prim [rows,W,2], prim_t, stats dict)"""
+                    want_radiance=False, want_primary=False, row_stride: int = 1, out=None):
+        """-> dict(bgr uint8 [rows,W,3], radiance, prim [rows,W,2], prim_t, stats dict); ``out``: a C-contiguous
+        uint8 array [rows,W,3] (e.g. a block of rows of the caller's image) that receives the pixels in place"""
         opts = make_opts(options, seed, row_stride=row_stride)
         W = opts.width
         nrows = (opts.height - row0 + row_stride - 1) // row_stride if nrows is None else nrows
-        bgr = np.empty((nrows, W, 3), np.uint8)
+        if out is None:
+            bgr = np.empty((nrows, W, 3), np.uint8)
+        else:
+            bgr = out
+            if bgr.dtype != np.uint8 or bgr.shape != (nrows, W, 3) or not bgr.flags.c_contiguous or not bgr.flags.writeable:
+                raise ValueError(f"out must be a writable C-contiguous uint8 array of shape {(nrows, W, 3)}")
         rad = np.empty((nrows, W, 3), np.float32) if want_radiance else None
         prim = np.empty((nrows, W, 2), np.int32) if want_primary else None
         prim_t = np.empty((nrows, W), np.float32) if want_primary else None

@@ -416,8 +416,9 @@ class Photon:
             progress[sid] = 0
             if failed:
                 continue
-            out = ctx.render_rows(native_opts, seed=seed, row0=sid * stripe_rows, nrows=stripe_rows)
-            image[sid * stripe_rows:(sid + 1) * stripe_rows] = out["bgr"]
+            # a stripe is a block of whole rows of the image: the library writes it in place
+            out = ctx.render_rows(native_opts, seed=seed, row0=sid * stripe_rows, nrows=stripe_rows,
+                                  out=image[sid * stripe_rows:(sid + 1) * stripe_rows])
             for k, v in out["stats"].items():
                 if isinstance(v, list):      # per-level arrays
                     totals[k] = [a + b for a, b in zip(totals.get(k, [0] * len(v)), v)]
