@@ -194,6 +194,14 @@ def test_errors_are_reported(gpu_ctx):
         gpu_ctx.render_rows(dict(width=8, height=8, bounces=15))
     with pytest.raises(_native.NativeError, match="row range"):
         gpu_ctx.render_rows(dict(width=8, height=8, bounces=1), row0=4, nrows=8)
+    # pixels written in place: the destination must be exactly the block of rows asked for
+    image = np.zeros((8, 8, 3), np.uint8)
+    got = gpu_ctx.render_rows(dict(width=8, height=8, bounces=1), row0=4, nrows=4, out=image[4:])
+    assert got["bgr"].base is image and np.array_equal(image[4:], gpu_ctx.render_rows(dict(width=8, height=8, bounces=1), row0=4, nrows=4)["bgr"])
+    assert (image[:4] == 0).all() and image[4:].any()
+    for bad in (image[3:], image[4:, :, :2], image[4:].astype(np.int8), image[::2]):
+        with pytest.raises(ValueError, match="out must be"):
+            gpu_ctx.render_rows(dict(width=8, height=8, bounces=1), row0=4, nrows=4, out=bad)
     fresh = _native.Context(0)
     with pytest.raises(_native.NativeError, match="no scene"):
         fresh.render_rows(dict(width=8, height=8))
