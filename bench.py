@@ -230,6 +230,8 @@ def main():
                          "measured_on": "one frame alone on the device, after the timed steps"},
             # the whole pipeline as timed: every flop of the frame over the time a frame takes with F in flight
             "pipeline": {"frames_in_flight": F, "frame_latency_ms": round(last["ms_device"], 4),
+                         # this rank's share of one frame with nothing else on the device, as a rate
+                         "frame_alone_mrays": round(last["queries"] / (last["ms_device"] * 1e-3) / 1e6, 2) if last["ms_device"] > 0 else None,
                          "achieved": round(flops / (ms_per_step * 1e-3) / 1e12, 3), "unit": "TFLOP/s",
                          "frac": round(flops / (ms_per_step * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 4)},
         }
