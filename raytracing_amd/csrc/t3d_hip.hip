@@ -158,7 +158,9 @@ struct NodePool {
 
 // Queue counters.  Same-address device-scope atomics retire at roughly one per 7 ns on this chip, so one
 // counter per level would serialise the kernel: every level has T3D_SHARDS counters, each in its own
-// 64-byte line, and wave w only ever touches shard w % T3D_SHARDS.
+// 64-byte line, and wave w only ever touches shard w % T3D_SHARDS.  Workgroups go to the eight XCDs in turn and a
+// grid holds a multiple of 16 workgroups (64 waves), so shard s is read and written on XCD (s / 4) % 8 in every launch:
+// the rays and nodes one level appends are found in the same XCD's L2 by the next level and by k_resolve.
 struct alignas(64) PaddedCount {
     int v;
     int pad[15];
