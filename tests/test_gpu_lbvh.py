@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import flat_for, golden_names, load_golden
-from test_gpu_parity import EDGE_TIE_MARGIN, LSB_OK_FRACTION, check_against_oracle
+from test_gpu_parity import EDGE_TIE_MARGIN, LSB_OK_FRACTION, check_against_oracle, check_growing_trees
 
 pytestmark = pytest.mark.gpu
 
@@ -40,6 +40,10 @@ def test_golden_cases_through_lbvh(name, lbvh_ctx, oracle_mod):
         assert st["rays_api"] == meta["rays"]
         ids_equal = (out["prim"][..., 0] == g["prim_obj"]) & (out["prim"][..., 1] == g["prim_face"])
         assert (~ids_equal & (frag > EDGE_TIE_MARGIN)).sum() == 0
+
+
+def test_maximum_bounces_and_growing_trees_through_lbvh(lbvh_ctx, oracle_mod):
+    check_growing_trees(lbvh_ctx, oracle_mod)
 
 
 def _soup(n_random, grid, n_spheres):

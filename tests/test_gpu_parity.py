@@ -186,10 +186,8 @@ def test_edge_cases(gpu_ctx, oracle_mod):
         check_against_oracle(out, ref, None, lights=opt.get("lights", True))
 
 
-def test_maximum_bounces_and_growing_trees(gpu_ctx, oracle_mod):
-    """Nested glass spheres: both children of most nodes hit glass again, so the levels grow far beyond the two rays per
-    primary sample the work buffers start with (the call grows them and traces the band again), up to the largest
-    number of bounces the library takes."""
+def nested_glass_scene():
+    """Six concentric glass spheres in front of the camera: both children of most nodes hit glass again."""
     from raytracing_amd.flatten import flatten_scene
     from raytracing_amd.scene import RGB, Camera, Light, Material, Scale, Scene, Shader, Sphere, Vec3
     s = Scene()
@@ -200,14 +198,24 @@ def test_maximum_bounces_and_growing_trees(gpu_ctx, oracle_mod):
         ball.setShader(Shader(color=RGB(200, 220, 250), roughness=0.0, reflectivity=0.5))
         ball.material = Material(ior=1.3)
     Light(s, position=Vec3(4, 5, -2), strength=1.0)
-    flat = flatten_scene(s)
-    gpu_ctx.upload(flat)
+    return flatten_scene(s)
+
+
+def check_growing_trees(ctx, oracle_mod):
+    """The levels grow far beyond the two rays per primary sample the work buffers start with (the call grows them
+    and traces the band again), up to the largest number of bounces the library takes."""
+    flat = nested_glass_scene()
+    ctx.upload(flat)
     for opt in (dict(width=24, height=16, bounces=14), dict(width=24, height=16, bounces=9, samples=3)):
-        out = gpu_ctx.render_rows(opt, seed=2, want_radiance=True, want_primary=True)
+        out = ctx.render_rows(opt, seed=2, want_radiance=True, want_primary=True)
         ref = oracle_mod.render(flat, opt, seed=2)
-        assert ref["stats"]["trace_queries"] > 20 * opt["width"] * opt["height"] * opt.get("samples", 1)   # far more than two rays per sample and level
+        assert ref["stats"]["trace_queries"] > 20 * opt["width"] * opt["height"] * opt.get("samples", 1)
         check_against_oracle(out, ref, None)
         assert out["stats"]["nodes"] == ref["stats"]["nodes"]
+
+
+def test_maximum_bounces_and_growing_trees(gpu_ctx, oracle_mod):
+    check_growing_trees(gpu_ctx, oracle_mod)
 
 
 def test_errors_are_reported(gpu_ctx):
