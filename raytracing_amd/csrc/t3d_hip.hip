@@ -1387,6 +1387,8 @@ extern "C" int t3d_create(int device, t3d_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_sm = prop.multiProcessorCount;
     if (getenv("T3D_NO_GRAPHS")) c->graphs_enabled = false;
+    // working-set budget of one band in MiB (default 48 GiB): small values make small frames take the paths of huge ones
+    if (const char* mb = getenv("T3D_MEM_BUDGET_MB")) { const long v = atol(mb); if (v > 0) c->mem_budget = (size_t)v << 20; }
     if (hipMalloc((void**)&c->d_cnt_pair[0], sizeof(Counters)) != hipSuccess || hipMalloc((void**)&c->d_cnt_pair[1], sizeof(Counters)) != hipSuccess ||
         hipMemset(c->d_cnt_pair[0], 0, sizeof(Counters)) != hipSuccess || hipMemset(c->d_cnt_pair[1], 0, sizeof(Counters)) != hipSuccess ||
         hipMalloc((void**)&c->d_fetch, sizeof(PaddedCount) * (T3D_MAX_BOUNCES + 2) * 2 * T3D_SHARDS) != hipSuccess ||
@@ -2013,9 +2015,13 @@ extern "C" int t3d_render_rows_device(t3d_ctx* c, const t3d_opts* o, int row0, i
             rc = render_band(c, o, row0 + r * (o->row_stride > 1 ? o->row_stride : 1), nb, factor, bgr_device + 3 * off, radiance_device ? radiance_device + 3 * off : nullptr,
                              primary_device ? primary_device + 2 * off : nullptr, primary_t_device ? primary_t_device + off : nullptr, st,
                              stats ? &band_stats : nullptr, nullptr, nullptr, 0);
-            if (rc == T3D_E_CAPACITY && factor < (1 << o->bounces)) {
-                size_t need = (size_t)nb * o->width * S * (size_t)factor * 2 * per_sample / 2;
-                if (need > c->mem_budget && nb > 1) { nb = (nb + 1) / 2; continue; }
+            // a level holds at most 2^bounces rays per sample; a band of few samples is worked on by few waves, whose
+            // rays all land in those waves' shards, so the bound on the factor counts every shard
+            if (rc == T3D_E_CAPACITY && factor < (1 << o->bounces) * T3D_SHARDS) {
+                const size_t next_cap = (size_t)nb * o->width * S * (size_t)factor * 2;   // entries per level after doubling
+                size_t need = next_cap * per_sample / 2;
+                // fewer rows instead, where doubling would leave the budget or the 32-bit node indices
+                if ((need > c->mem_budget || next_cap * (size_t)levels > (size_t)0x7FFFFFF0) && nb > 1) { nb = (nb + 1) / 2; continue; }
                 factor *= 2;
                 continue;
             }

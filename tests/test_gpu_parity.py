@@ -218,6 +218,30 @@ def test_maximum_bounces_and_growing_trees(gpu_ctx, oracle_mod):
     check_growing_trees(gpu_ctx, oracle_mod)
 
 
+def test_small_memory_budget_splits_the_frame(gpu_ctx, monkeypatch):
+    """With a working-set budget of 1 MiB the frame is cut into bands of a few rows, and bands whose trees outgrow the
+    budget are halved: same pixels and the same counts as the frame in one piece."""
+    from raytracing_amd import _native
+    flat = nested_glass_scene()
+    opt = dict(width=24, height=16, bounces=9, samples=2)
+    gpu_ctx.upload(flat)
+    whole = gpu_ctx.render_rows(opt, seed=5, want_radiance=True, want_primary=True)
+    monkeypatch.setenv("T3D_MEM_BUDGET_MB", "1")
+    small = _native.Context(0)
+    try:
+        small.upload(flat)
+        cut = small.render_rows(opt, seed=5, want_radiance=True, want_primary=True)
+        part = small.render_rows(opt, seed=5, row0=5, nrows=7)
+    finally:
+        small.close()
+    assert cut["stats"]["launches"] > 3 * whole["stats"]["launches"]        # many bands
+    for k in ("bgr", "radiance", "prim", "prim_t"):
+        assert np.array_equal(cut[k], whole[k], equal_nan=(k == "prim_t")), k
+    for k in ("queries", "rays_api", "nodes", "shadow_queries", "trace_queries"):
+        assert cut["stats"][k] == whole["stats"][k], k
+    assert np.array_equal(part["bgr"], whole["bgr"][5:12])
+
+
 def test_errors_are_reported(gpu_ctx):
     from raytracing_amd import _native
     flat = flat_for("cornellScene.json")
