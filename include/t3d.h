@@ -166,7 +166,10 @@ int t3d_render_rows(t3d_ctx* ctx, const t3d_opts* opts, int row0, int nrows, uin
 /*
  * Same work, outputs left in device memory owned by the caller (e.g. a torch tensor's data
  * pointer) and launched on `stream` (a hipStream_t passed as void*, NULL = the context's own
- * stream).  Does not synchronise unless `stats` is non-NULL.
+ * stream).  Does not synchronise unless `stats` is non-NULL.  Only a call with `stats` can see that a
+ * trace tree outgrew the work buffers and trace the band again with larger ones; a call without leaves
+ * that to the caller: t3d_last_call_stats afterwards returns T3D_E_CAPACITY (the output of that call is
+ * then invalid; a call with `stats` on the same context grows the buffers for the calls after it).
  */
 int t3d_render_rows_device(t3d_ctx* ctx, const t3d_opts* opts, int row0, int nrows,
                            uint8_t* bgr_device, float* radiance_device, int32_t* primary_device,
