@@ -52,7 +52,7 @@
 
 #define T3D_BLOCK 256
 #define T3D_WAVES (T3D_BLOCK / 64)
-#define T3D_MAX_LIGHTS 64
+#define T3D_MAX_LIGHTS 4096 /* every emissive face is a light (T3DR.py:789-816); 4 bytes per (node, light) */
 #define T3D_MAX_BOUNCES 14 /* heap index of the deepest node must fit 16 bits of the RNG key */
 #define T3D_SHARDS 64      /* queue shards per level; every launch holds a multiple of 64 waves */
 #define T3D_RING 256       /* nodes per wave in the brute-force kernels: < 128 pairs pending before a trace round, which adds <= 128 nodes */
@@ -1448,7 +1448,7 @@ static int upload(t3d_ctx* c, void** dst, const std::vector<T>& v) {
 extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
     if (!c) return T3D_E_INVALID;
     if (!s || s->n_objects < 0 || s->n_tris < 0 || s->n_shaders < 0 || s->n_lights < 0) { c->err = "t3d_upload_scene: bad description"; return T3D_E_INVALID; }
-    if (s->n_lights > T3D_MAX_LIGHTS) { c->err = "t3d_upload_scene: too many lights (limit 64)"; return T3D_E_CAPACITY; }
+    if (s->n_lights > T3D_MAX_LIGHTS) { c->err = "t3d_upload_scene: too many lights (limit 4096)"; return T3D_E_CAPACITY; }
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_scene(c);

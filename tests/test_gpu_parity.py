@@ -472,6 +472,39 @@ def test_many_lights(gpu_ctx, oracle_mod, accel):
     assert out["stats"]["shadow_queries"] == len(flat.light_strength) * out["stats"]["nodes"]
 
 
+def test_hundreds_of_lights(gpu_ctx, oracle_mod):
+    """Every face of an emissive mesh is a light (T3DR.py:789-816): the monkey's 968 faces through the LBVH path, and
+    eighty Light objects through the brute-force path -- more pairs per node than a shadow round holds."""
+    from raytracing_amd.flatten import flatten_scene
+    from raytracing_amd.scene import RGB, Light, Shader, Vec3
+    from raytracing_amd.workloads import cornell_scene
+    scene = cornell_scene(with_light=False, suzanne=True)
+    monkey = [o for o in scene.objects if o.name == "Monkey"][0]
+    monkey.setShader(Shader(color=RGB(255, 240, 200), emissionStrength=0.02))
+    flat = flatten_scene(scene)
+    assert len(flat.light_strength) > 900 and flat.n_tris > 256
+    gpu_ctx.upload(flat)
+    opt = dict(width=20, height=12, bounces=1, ambient=(16, 16, 16))
+    out = gpu_ctx.render_rows(opt, seed=1, want_radiance=True, want_primary=True)
+    ref = oracle_mod.render(flat, opt, seed=1)
+    check_against_oracle(out, ref, oracle_mod.primary_fragility(flat, opt))
+    assert out["stats"]["shadow_queries"] == len(flat.light_strength) * out["stats"]["nodes"] > 0
+
+    scene = cornell_scene(with_light=True)
+    rng = np.random.default_rng(8)
+    for i in range(80):
+        p = rng.uniform(-2.5, 2.5, 3)
+        Light(scene=scene, name=f"extra{i}", position=Vec3(float(p[0]), float(p[1]), float(1.0 + p[2])), strength=float(rng.uniform(0.02, 0.1)))
+    flat = flatten_scene(scene)
+    assert len(flat.light_strength) > 80 and flat.n_tris + flat.n_spheres <= 256
+    gpu_ctx.upload(flat)
+    opt = dict(width=40, height=24, bounces=2, ambient=(16, 16, 16))
+    out = gpu_ctx.render_rows(opt, seed=1, want_radiance=True, want_primary=True)
+    ref = oracle_mod.render(flat, opt, seed=1)
+    check_against_oracle(out, ref, oracle_mod.primary_fragility(flat, opt))
+    assert out["stats"]["aabb_tests"] == 0 and out["stats"]["shadow_queries"] == len(flat.light_strength) * out["stats"]["nodes"]
+
+
 def test_device_outputs_follow_the_callers_stream(gpu_ctx):
     """Asynchronous device-output calls on an explicit stream: every call's output is complete for what the caller
     queues behind it on that stream, call after call into the same buffers; with an odd row count, a row stride and an
