@@ -472,6 +472,42 @@ def test_many_lights(gpu_ctx, oracle_mod, accel):
     assert out["stats"]["shadow_queries"] == len(flat.light_strength) * out["stats"]["nodes"]
 
 
+@pytest.mark.parametrize("accel", ["brute", "lbvh"])
+def test_degenerate_geometry(gpu_ctx, oracle_mod, accel):
+    """Faces with two equal corners or three collinear ones (zero normal: never hit, T3DR.py:630-632), a mesh without
+    faces, a sphere of radius zero, a light of strength zero -- next to ordinary geometry."""
+    from raytracing_amd.flatten import flatten_scene
+    from raytracing_amd.scene import RGB, Camera, Light, Material, Mesh, Object, Scale, Scene, Shader, Sphere, Vec3
+    s = Scene()
+    # off the wall's symmetry axes: from (0, 0, -6) a diagonal of pixel rays meets the shared edge of the wall's two
+    # triangles exactly, where float32 and float64 may decide the strict interior test differently
+    Camera(s, position=Vec3(0.137, 0.071, -6), length=20)
+    verts = [Vec3(-2, -2, 2), Vec3(2, -2, 2), Vec3(2, 2, 2), Vec3(-2, 2, 2), Vec3(0, 0, 1), Vec3(1, 1, 1),
+             Vec3(-3, -2.5, 0), Vec3(3, -2.5, 0), Vec3(3, -2.5, 6), Vec3(-3, -2.5, 6)]
+    faces = [(0, 2, 1), (0, 3, 2), (4, 4, 5), (4, 5, 4), (0, 2, 0), (4, 5, 2), (6, 7, 8), (6, 8, 9)]
+    wall = Object(scene=s, name="wall and floor", mesh=Mesh(verts, faces))
+    wall.setShader(Shader(color=RGB(220, 180, 90), roughness=0.6, reflectivity=0.7))
+    Object(scene=s, name="no faces", mesh=Mesh([], []))
+    dot = Sphere(s, position=Vec3(1, 0, 0.5))
+    dot.scale = Scale(0, 0, 0)
+    ball = Sphere(s, position=Vec3(-1, -1.5, 1))
+    ball.scale = Scale(1.5, 1.5, 1.5)
+    ball.setShader(Shader(color=RGB(90, 180, 220), roughness=0.1, reflectivity=0.4))
+    ball.material = Material(ior=1.5)
+    Light(s, position=Vec3(0, 3, 0), strength=0.0)
+    Light(s, position=Vec3(2, 3, -1), strength=1.2)
+    flat = flatten_scene(s)
+    gpu_ctx.set_accel(accel)
+    gpu_ctx.upload(flat)
+    gpu_ctx.set_accel("auto")
+    opt = dict(width=40, height=30, bounces=3, samples=2, ambient=(250, 0, 40))
+    out = gpu_ctx.render_rows(opt, seed=3, want_radiance=True, want_primary=True)
+    ref = oracle_mod.render(flat, opt, seed=3)
+    check_against_oracle(out, ref, oracle_mod.primary_fragility(flat, opt))
+    assert not np.isin(out["prim"][..., 1], (2, 3, 4, 5)).any()      # no pixel sees a degenerate face
+    assert (out["prim"][..., 0] >= 0).sum() > 200
+
+
 def test_hundreds_of_lights(gpu_ctx, oracle_mod):
     """Every face of an emissive mesh is a light (T3DR.py:789-816): the monkey's 968 faces through the LBVH path, and
     eighty Light objects through the brute-force path -- more pairs per node than a shadow round holds."""
