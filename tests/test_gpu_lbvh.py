@@ -46,6 +46,47 @@ def test_maximum_bounces_and_growing_trees_through_lbvh(lbvh_ctx, oracle_mod):
     check_growing_trees(lbvh_ctx, oracle_mod)
 
 
+@pytest.mark.parametrize("accel", ["brute", "lbvh"])
+def test_coincident_primitives_keep_the_reference_order(accel, oracle_mod):
+    """Two hundred copies of one triangle, each with corners and a shader of its own, and three spheres in one place:
+    every copy is hit at the same distance and the first one in face order wins (T3DR.py:715), whatever order
+    the hierarchy (whose sort keys all collide) or the plane groups visit them in."""
+    from raytracing_amd import _native
+    from raytracing_amd.flatten import flatten_scene
+    from raytracing_amd.scene import RGB, Camera, Light, Mesh, Object, Scale, Scene, Shader, Sphere, Vec3
+    s = Scene()
+    Camera(s, position=Vec3(0.11, 0.07, -6), length=20)
+    verts, faces = [], []
+    for k in range(200):
+        verts += [Vec3(-2, -2, 2), Vec3(2, 2, 2), Vec3(2, -2, 2)]
+        faces.append((3 * k, 3 * k + 1, 3 * k + 2))
+    verts += [Vec3(-2, -2, 2.5), Vec3(-2, 2, 2.5), Vec3(2, 2, 2.5)]      # another triangle behind, seen beside the stack
+    faces.append((600, 601, 602))
+    stack = Object(scene=s, name="stack", mesh=Mesh(verts, faces))
+    for k in range(201):
+        stack.setShader(Shader(name=f"s{k}", color=RGB(10 + k, 250 - k, 30 + (k * 7) % 200), roughness=0.8, reflectivity=0.9), faces=[k])
+    for k in range(3):
+        ball = Sphere(s, name=f"ball{k}", position=Vec3(-1.2, 1.2, 1.0))
+        ball.scale = Scale(1, 1, 1)
+        ball.setShader(Shader(color=RGB(250 - 100 * k, 40 + 100 * k, 40), roughness=0.5, reflectivity=0.8))
+    Light(s, position=Vec3(0, 1, -3), strength=1.0)
+    flat = flatten_scene(s)
+    ctx = _native.Context(0)
+    try:
+        ctx.set_accel(accel)
+        ctx.upload(flat)
+        opt = dict(width=48, height=36, bounces=2, samples=1)
+        out = ctx.render_rows(opt, seed=6, want_radiance=True, want_primary=True)
+    finally:
+        ctx.close()
+    ref = oracle_mod.render(flat, opt, seed=6)
+    check_against_oracle(out, ref, oracle_mod.primary_fragility(flat, opt))
+    seen = out["prim"][..., 1][out["prim"][..., 0] == 1]          # faces of the stack object seen by primary rays
+    assert set(np.unique(seen)) == {0, 200}                         # the first copy and the triangle behind, no other copy
+    balls = np.unique(out["prim"][..., 0][out["prim"][..., 1] == -1])
+    assert [int(b) for b in balls if 2 <= b <= 4] == [2]           # the first of the three spheres (object 5 is the Light)
+
+
 def _soup(n_random, grid, n_spheres):
     from raytracing_amd.flatten import flatten_scene
     from raytracing_amd.workloads import synthetic_scene
