@@ -87,6 +87,35 @@ def test_coincident_primitives_keep_the_reference_order(accel, oracle_mod):
     assert [int(b) for b in balls if 2 <= b <= 4] == [2]           # the first of the three spheres (object 5 is the Light)
 
 
+def test_tiny_scenes_through_lbvh(lbvh_ctx, oracle_mod):
+    """No primitive at all, one, two, three: hierarchies of zero, zero, one and two inner nodes."""
+    from raytracing_amd.flatten import flatten_scene
+    from raytracing_amd.scene import RGB, Camera, Light, Mesh, Object, Scale, Scene, Shader, Sphere, Vec3
+    s = Scene()
+    Camera(s, position=Vec3(0.13, 0.05, -5), length=20)
+    opt = dict(width=21, height=13, bounces=2, samples=2, ambient=(9, 8, 7))
+
+    def check():
+        flat = flatten_scene(s)
+        lbvh_ctx.upload(flat)
+        out = lbvh_ctx.render_rows(opt, seed=4, want_radiance=True, want_primary=True)
+        check_against_oracle(out, oracle_mod.render(flat, opt, seed=4), oracle_mod.primary_fragility(flat, opt))
+        return out
+
+    out = check()
+    assert (out["bgr"] == np.array([7, 8, 9], np.uint8)).all()
+    ball = Sphere(s, position=Vec3(0, 0, 3))
+    ball.scale = Scale(2, 2, 2)
+    ball.setShader(Shader(color=RGB(250, 10, 10), roughness=0.3, reflectivity=0.6))
+    assert (check()["prim"][..., 0] == 1).any()
+    Light(s, position=Vec3(2, 3, -1), strength=1.5)                  # a Light is a primitive too
+    check()
+    tri = Object(scene=s, name="tri", mesh=Mesh([Vec3(-3, -1.5, 0), Vec3(3, -1.5, 0), Vec3(0, -1.5, 8)], [(0, 2, 1)]))
+    tri.setShader(Shader(color=RGB(90, 200, 90), roughness=0.9, reflectivity=0.5))
+    out = check()
+    assert (out["prim"][..., 0] == 3).any() and out["stats"]["aabb_tests"] > 0
+
+
 def _soup(n_random, grid, n_spheres):
     from raytracing_amd.flatten import flatten_scene
     from raytracing_amd.workloads import synthetic_scene
