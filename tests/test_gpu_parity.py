@@ -212,6 +212,16 @@ def check_growing_trees(ctx, oracle_mod):
         assert ref["stats"]["trace_queries"] > 20 * opt["width"] * opt["height"] * opt.get("samples", 1)
         check_against_oracle(out, ref, None)
         assert out["stats"]["nodes"] == ref["stats"]["nodes"]
+    # the tree of one pixel at fourteen bounces: hundreds of nodes, all in one queue shard
+    opt = dict(width=24, height=16, bounces=14)
+    ref = oracle_mod.render(flat, opt, seed=2, row0=8, nrows=1, want_nodes=True, node_cap=200000)
+    want = {int(n["heap"]): n for n in ref["nodes"] if (int(n["px"]), int(n["py"]), int(n["sample"])) == (12, 8, 0)}
+    nodes = ctx.trace_pixel(opt, 12, 8, 0, seed=2)
+    assert len(want) > 500 and sorted(n.heap for n in nodes) == sorted(want)
+    for n in nodes:
+        w = want[n.heap]
+        assert (n.obj, n.direction) == (int(w["obj"]), int(w["direction"]))
+        assert np.allclose(list(n.color), w["color"], atol=RADIANCE_TOL)
 
 
 def test_maximum_bounces_and_growing_trees(gpu_ctx, oracle_mod):
