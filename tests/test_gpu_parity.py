@@ -652,3 +652,52 @@ def test_replayed_bands_match_fresh_ones(gpu_ctx):
     assert not np.array_equal(want3["bgr"], want1["bgr"])
     for f in changed:
         assert np.array_equal(f.cpu().numpy(), want3["bgr"])
+
+
+def test_contexts_on_two_host_threads(gpu_ctx):
+    """One host thread per context, several contexts at once: two threads, each with a context, a stream and a scene of
+    its own, issue asynchronous bands (launched kernel by kernel, then captured, then replayed) at the same time."""
+    import threading
+    import torch
+    from raytracing_amd import _native
+    dev = torch.device("cuda", 0)
+    jobs = [("config2_cornell_light.json", dict(width=160, height=96, bounces=3, samples=1), 1),
+            ("cornellScene.json", dict(width=128, height=80, bounces=2, samples=2), 7)]
+    results, errors = [None, None], []
+
+    def work(k):
+        try:
+            scene_file, opt, seed = jobs[k]
+            ctx = _native.Context(0)
+            try:
+                ctx.upload(flat_for(scene_file))
+                ctx.set_timing(False)
+                stream = torch.cuda.Stream(dev)
+                bgr = torch.zeros((opt["height"], opt["width"], 3), dtype=torch.uint8, device=dev)
+                frames = []
+                with torch.cuda.stream(stream):
+                    for _ in range(10):
+                        bgr.zero_()
+                        ctx.render_rows_device(opt, seed, 0, opt["height"], bgr.data_ptr(), stream=stream.cuda_stream, want_stats=False)
+                        frames.append(bgr.clone())
+                    stream.synchronize()
+                st = ctx.last_call_stats()
+                results[k] = ([f.cpu().numpy() for f in frames], st)
+            finally:
+                ctx.close()
+        except Exception as e:   # noqa: BLE001 - reported by the main thread
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(100)
+    assert not errors and not any(t.is_alive() for t in threads), errors
+    for k, (scene_file, opt, seed) in enumerate(jobs):
+        gpu_ctx.upload(flat_for(scene_file))
+        want = gpu_ctx.render_rows(opt, seed=seed)
+        frames, st = results[k]
+        for f in frames:
+            assert np.array_equal(f, want["bgr"])
+        assert st["queries"] == want["stats"]["queries"]
