@@ -43,6 +43,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <cmath>
 #include <map>
 #include <string>
 #include <tuple>
@@ -1449,6 +1450,16 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
     if (!c) return T3D_E_INVALID;
     if (!s || s->n_objects < 0 || s->n_tris < 0 || s->n_shaders < 0 || s->n_lights < 0) { c->err = "t3d_upload_scene: bad description"; return T3D_E_INVALID; }
     if (s->n_lights > T3D_MAX_LIGHTS) { c->err = "t3d_upload_scene: too many lights (limit 4096)"; return T3D_E_CAPACITY; }
+    {
+        // geometry that is not a finite number has no place in a hierarchy or a plane group: refuse it by name
+        auto finite = [](const double* p, size_t n) { if (p) for (size_t i = 0; i < n; ++i) if (!std::isfinite(p[i])) return false; return true; };
+        const char* bad = !finite(s->tri_verts, (size_t)s->n_tris * 9) ? "a triangle corner"
+                        : !finite(s->obj_center, (size_t)s->n_objects * 3) ? "an object position"
+                        : !finite(s->obj_radius, (size_t)s->n_objects) ? "an object radius"
+                        : !finite(s->light_pos, (size_t)s->n_lights * 3) ? "a light position"
+                        : !finite(s->cam_pos, 3) || !finite(s->cam_euler, 3) || !finite(&s->cam_zlen, 1) ? "the camera" : nullptr;
+        if (bad) { c->err = std::string("t3d_upload_scene: ") + bad + " is not finite"; return T3D_E_INVALID; }
+    }
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_scene(c);

@@ -268,6 +268,14 @@ def test_errors_are_reported(gpu_ctx):
     for bad in (image[3:], image[4:, :, :2], image[4:].astype(np.int8), image[::2]):
         with pytest.raises(ValueError, match="out must be"):
             gpu_ctx.render_rows(dict(width=8, height=8, bounces=1), row0=4, nrows=4, out=bad)
+    # geometry that is not a number is refused at upload, and the scene uploaded before stays in place
+    import copy
+    broken = copy.deepcopy(flat)
+    broken.tri_verts = broken.tri_verts.copy()
+    broken.tri_verts.flat[7] = np.nan
+    with pytest.raises(_native.NativeError, match="triangle corner is not finite"):
+        gpu_ctx.upload(broken)
+    gpu_ctx.upload(flat)
     fresh = _native.Context(0)
     with pytest.raises(_native.NativeError, match="no scene"):
         fresh.render_rows(dict(width=8, height=8))
