@@ -1,5 +1,5 @@
 """What one rank of an N-GPU run does per frame, timed on one GPU: rows r, r+N, ... of the benchmark frame
-; usage: rank_emulation.py [workload] [fF] [g] [N ...]; fF: F frames in flight, each with a context and a
+; usage: rank_emulation.py [workload] [fF] [a] [g] [N ...]; fF: F frames in flight, each with a context and a
 stream of its own (default f1); g: every frame is followed by a gather in a one-rank RCCL group and the strided
 copy into the frame, on the frame's stream (the host-side cost of the real gather; no bytes cross a link).
 Shows the fixed per-frame cost that limits strong scaling."""
@@ -16,6 +16,9 @@ if args and not args[0].isdigit() and not (args[0][0] == "f" and args[0][1:].isd
 F = 1
 if args and args[0].startswith("f"):
     F = int(args.pop(0)[1:])
+adaptive = bool(args) and args[0] == "a"      # a: keep the adaptive cut of small launches whatever F is
+if adaptive:
+    args.pop(0)
 with_gather = bool(args) and args[0] == "g"
 if with_gather:
     args.pop(0)
@@ -26,7 +29,7 @@ flat, opt = get_flat_workload(workload)
 ctx = _native.Context(0); ctx.upload(flat)
 more = [_native.Context(0) for _ in range(F - 1)]
 for c in [ctx] + more:
-    c.set_full_rounds(F >= 3)
+    c.set_full_rounds(F >= 3 and not adaptive)
 for c in more:
     c.upload(flat); c.set_timing(False)
 more_streams = [torch.cuda.Stream(torch.device("cuda", 0)) for _ in range(F - 1)]
