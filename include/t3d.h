@@ -99,8 +99,9 @@ typedef struct t3d_stats {
     uint64_t queries;        /* closest-hit queries: primary + bounce + transmit + shadow            */
     uint64_t trace_queries;  /* of which tree rays (primary, bounce, transmit)                        */
     uint64_t shadow_queries; /* of which shadow rays (one per light per shaded node)                  */
-    uint64_t tri_tests;      /* ray-triangle tests executed                                          */
-    uint64_t sphere_tests;   /* ray-sphere tests executed                                            */
+    uint64_t tri_tests;      /* ray-triangle tests: counted by the LBVH traversal; on the brute-force path
+                                queries x triangles (plane groups a whole wave skips are not subtracted)  */
+    uint64_t sphere_tests;   /* ray-sphere tests, likewise                                           */
     uint64_t aabb_tests;     /* ray-box tests executed                                               */
     uint64_t nodes;          /* shaded trace-tree nodes (emitter leaves are folded into the parent)  */
     uint64_t launches;       /* kernel launches issued                                               */
