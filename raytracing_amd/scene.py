@@ -435,7 +435,13 @@ def _read_stl_triangles(filename):
             return tris
     corners = [tuple(float(v) for v in line.split()[1:4])
                for line in data.decode("ascii", "replace").splitlines() if line.strip().startswith("vertex")]
-    return [tuple(corners[i:i + 3]) for i in range(0, len(corners) - 2, 3)]
+    if not corners and data.strip() and b"facet" not in data and b"endsolid" not in data:
+        # neither the size a binary file's facet count implies nor a single ASCII vertex: a cut-off or foreign file
+        raise ValueError(f"{filename}: not a complete binary STL file (size {len(data)} does not fit its facet count) "
+                         "and not an ASCII one")
+    if len(corners) % 3:
+        raise ValueError(f"{filename}: ASCII STL with {len(corners)} vertex lines, not a multiple of three")
+    return [tuple(corners[i:i + 3]) for i in range(0, len(corners), 3)]
 
 
 class Mesh:

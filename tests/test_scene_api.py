@@ -209,3 +209,32 @@ def test_flat_scene_digest_tracks_every_input():
     d = T3DE.Scene.fromJSON(path)
     next(o for o in d.objects if o.type == "mesh").shaders[0].roughness += 0.25
     assert flatten_scene(d).digest() != base
+
+
+def test_stl_reader_ascii_binary_and_cut_off_files(tmp_path):
+    """Binary files (also with a header that starts with the word "solid") and ASCII files give the same mesh; a file
+    that is neither -- a binary file cut short -- is refused instead of read as an empty mesh."""
+    import struct
+    from raytracing_amd.scene import Mesh
+    tris = [((0, 0, 0), (1, 0, 0), (0, 1, 0)), ((0, 0, 0), (0, 1, 0), (0, 0, 1)), ((0, 0, 0), (0, 0, 1), (1, 0, 0)),
+            ((1, 0, 0), (0, 0, 1), (0, 1, 0))]
+    ascii_file, binary_file, cut_file, odd_file = (tmp_path / n for n in ("a.stl", "b.stl", "c.stl", "d.stl"))
+    lines = ["solid t"]
+    for t in tris:
+        lines += [" facet normal 0 0 0", "  outer loop"] + ["   vertex %g %g %g" % v for v in t] + ["  endloop", " endfacet"]
+    ascii_file.write_text("\n".join(lines + ["endsolid t"]) + "\n")
+    blob = b"solid is how this binary header starts".ljust(80, b" ") + struct.pack("<I", len(tris))
+    for t in tris:
+        blob += struct.pack("<3f", 0, 0, 0) + b"".join(struct.pack("<3f", *v) for v in t) + struct.pack("<H", 0)
+    binary_file.write_bytes(blob)
+    a, b = Mesh.fromSTL(str(ascii_file)), Mesh.fromSTL(str(binary_file))
+    assert a.faces == b.faces and len(a.faces) == 4 and len(a.vertices) == 4
+    assert [(v.x, v.y, v.z) for v in a.vertices] == [(v.x, v.y, v.z) for v in b.vertices]
+    assert (a.vertices[1].x, a.vertices[1].y, a.vertices[1].z) == (1.0, 0.0, 0.0)
+    assert (a.vertices[2].x, a.vertices[2].y, a.vertices[2].z) == (0.0, 0.0, 1.0)      # y and z exchanged
+    cut_file.write_bytes(blob[:150])
+    with pytest.raises(ValueError, match="not a complete binary STL"):
+        Mesh.fromSTL(str(cut_file))
+    odd_file.write_text("\n".join(lines[:-3]) + "\n")                                  # the last facet lost a vertex line
+    with pytest.raises(ValueError, match="multiple of three"):
+        Mesh.fromSTL(str(odd_file))
