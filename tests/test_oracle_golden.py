@@ -46,7 +46,7 @@ def test_oracle_reproduces_reference(name, oracle_mod):
 
 
 def test_known_image_digests():
-    """SHA-1 prefixes of the reference images quoted in the survey of the reference."""
+    """SHA-1 prefixes of the images the reference renders for G0 and G1 (recorded when the fixtures were made)."""
     import hashlib
     for name, digest in [("g0_cornell_160x120_b0", "157f954245a5"), ("g1_cornell_160x120_b1_mt", "1caea18147a0")]:
         g, meta = load_golden(name)
