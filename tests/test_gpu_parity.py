@@ -709,3 +709,16 @@ def test_contexts_on_two_host_threads(gpu_ctx):
         for f in frames:
             assert np.array_equal(f, want["bgr"])
         assert st["queries"] == want["stats"]["queries"]
+
+
+def test_random_scenes_on_both_paths(oracle_mod):
+    """Forty random scenes (triangle soups with several shaders, glass, emitters, spheres, zero to many lights) with
+    random sizes, bounces and samples, through the brute-force and the LBVH path against the oracle
+    (tools/fuzz_parity.py, which also says what a random scene is allowed that a fixture is not)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_parity
+    lines = []
+    fuzz_parity.run_cases(0, 40, report=lines.append)
+    assert len(lines) == 40

@@ -1,0 +1,120 @@
+"""Random scenes and options through both closest-hit paths of the HIP library against the CPU oracle.
+usage: fuzz_parity.py [first_seed] [count]; prints one line per case and exits non-zero on the first disagreement
+beyond the tolerances of tests/test_gpu_parity.py."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+
+def random_scene(seed):
+    from raytracing_amd.scene import RGB, Camera, Euler, Light, Material, Mesh, Object, Scale, Scene, Shader, Sphere, Vec3
+    rng = np.random.default_rng(seed)
+    s = Scene()
+    cam = Camera(s, position=Vec3(*(float(v) for v in rng.uniform(-0.5, 0.5, 3) + [0, 0, -7])), length=float(rng.uniform(30, 70)))
+    cam.rotation = Euler(*(float(v) for v in rng.uniform(-0.08, 0.08, 3)))
+
+    def shader():
+        glass = rng.random() < 0.35
+        return Shader(color=RGB(*(int(v) for v in rng.integers(20, 256, 3))), roughness=float(rng.choice([0.0, 0.2, 0.7, 1.0])),
+                      reflectivity=float(rng.choice([0.1, 0.5]) if glass else rng.choice([1.0, 1.0, 0.8, 0.0])),
+                      emissionStrength=float(0.4 if rng.random() < 0.06 else 0.0))
+
+    for m in range(int(rng.integers(1, 4))):
+        n = int(rng.integers(1, 40))
+        verts, faces = [], []
+        centre = rng.uniform(-2.5, 2.5, 3) + [0, 0, 2]
+        for k in range(n):
+            c = centre + rng.uniform(-1.5, 1.5, 3)
+            e1, e2 = rng.uniform(-1.2, 1.2, 3), rng.uniform(-1.2, 1.2, 3)
+            for p in (c, c + e1, c + e2):
+                verts.append(Vec3(*(float(v) for v in p)))
+            faces.append((3 * k, 3 * k + 1, 3 * k + 2))
+        o = Object(scene=s, name=f"mesh{m}", mesh=Mesh(verts, faces))
+        shaders = [shader() for _ in range(int(rng.integers(1, 4)))]
+        for k in range(n):
+            o.setShader(shaders[k % len(shaders)], faces=[k])
+        o.material = Material(ior=float(rng.choice([1.0, 1.3, 1.5])))
+    # a floor and a back wall, so that most rays end somewhere
+    room = Object(scene=s, name="room", mesh=Mesh([Vec3(-6, -3, -2), Vec3(6, -3, -2), Vec3(6, -3, 9), Vec3(-6, -3, 9),
+                                                  Vec3(-6, 6, 9), Vec3(6, 6, 9)], [(0, 2, 1), (0, 3, 2), (3, 4, 5), (3, 5, 2), (0, 1, 2), (0, 2, 3), (3, 5, 4), (3, 2, 5)]))   # both windings
+    room.setShader(Shader(color=RGB(200, 200, 190), roughness=1.0, reflectivity=1.0))
+    for b in range(int(rng.integers(0, 5))):
+        ball = Sphere(s, name=f"ball{b}", position=Vec3(*(float(v) for v in rng.uniform(-2.5, 2.5, 3) + [0, 0, 2.5])))
+        d = float(rng.uniform(0.4, 2.2))
+        ball.scale = Scale(d, d, d)
+        ball.setShader(shader())
+        ball.material = Material(ior=float(rng.choice([1.0, 1.33, 1.5])))
+    for l in range(int(rng.integers(0, 4))):
+        Light(s, name=f"light{l}", position=Vec3(*(float(v) for v in rng.uniform(-3, 3, 3) + [0, 3, 0])), strength=float(rng.uniform(0.3, 1.5)))
+    opt = dict(width=int(rng.integers(8, 90)), height=int(rng.integers(6, 60)), bounces=int(rng.integers(0, 6)),
+               samples=int(rng.integers(1, 4)), ambient=tuple(int(v) for v in rng.integers(0, 60, 3)), lights=bool(rng.random() < 0.85))
+    return s, opt
+
+
+def check_case(out, ref, frag, opt):
+    """The bars of tests/test_gpu_parity.py, with the allowances a random scene needs.  A secondary ray that grazes an
+    edge may hit in float32 and miss in float64 (or the other way round): one node more or less, and the pixel it
+    belongs to may move.  So one pixel (or 0.1 %) may differ, and the counts are compared to 0.1 %; primary hits away
+    from edges must be identical."""
+    from test_gpu_parity import EDGE_TIE_MARGIN, RADIANCE_TOL
+    allowed = max(1, out["bgr"].shape[0] * out["bgr"].shape[1] // 1000)
+    diff = np.abs(out["bgr"].astype(int) - ref["bgr"].astype(int)).max(axis=2)
+    assert (diff > 1).sum() <= allowed, f"{(diff > 1).sum()} pixels differ by more than 1 LSB"
+    err = np.abs(out["radiance"].astype(np.float64) - ref["radiance"]).max(axis=2)
+    assert (err > RADIANCE_TOL).sum() <= allowed, f"{(err > RADIANCE_TOL).sum()} pixels with a radiance error, max {err.max()}"
+    mism = (out["prim"] != ref["prim"]).any(axis=2) & (frag > EDGE_TIE_MARGIN)
+    assert mism.sum() == 0, f"{mism.sum()} primary-hit id mismatches away from triangle edges"
+    for k in ("rays_api", "queries") if opt["lights"] else ("rays_api",):   # lights off: the reference traces on behind emitters
+        assert abs(out["stats"][k] - ref["stats"][k]) <= max(2, ref["stats"][k] // 1000), (k, out["stats"][k], ref["stats"][k])
+
+
+def run_cases(first, count, report=print):
+    from oracle import oracle
+    from raytracing_amd import _native
+    from raytracing_amd.flatten import flatten_scene
+    oracle.build()
+    ctxs = {a: _native.Context(0) for a in ("brute", "lbvh")}
+    try:
+        for a, c in ctxs.items():
+            c.set_accel(a)
+        for seed in range(first, first + count):
+            scene, opt = random_scene(seed)
+            flat = flatten_scene(scene)
+            ref = oracle.render(flat, opt, seed=seed)
+            frag = oracle.primary_fragility(flat, opt)
+            counts = {}
+            for a, c in ctxs.items():
+                c.upload(flat)
+                out = c.render_rows(opt, seed=seed, want_radiance=True, want_primary=True)
+                try:
+                    check_case(out, ref, frag, opt)
+                    # the two paths evaluate the interior test differently (two in-plane coordinates against three):
+                    # they too may part ways at an edge, by as little
+                    counts[a] = out["stats"]["nodes"]
+                    assert abs(counts[a] - counts["brute"]) <= max(2, counts[a] // 1000), ("the two paths disagree", counts)
+                except AssertionError as e:
+                    raise AssertionError(f"seed {seed} {a}: {opt} tris {flat.n_tris} spheres {flat.n_spheres} "
+                                         f"lights {len(flat.light_strength)}: {str(e)[:300]}") from None
+            report(f"seed {seed}: {opt['width']}x{opt['height']} b{opt['bounces']} s{opt['samples']} tris {flat.n_tris} spheres {flat.n_spheres} "
+                   f"lights {len(flat.light_strength)} queries {ref['stats']['queries']} ok")
+    finally:
+        for c in ctxs.values():
+            c.close()
+
+
+def main():
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+    try:
+        run_cases(first, count, report=lambda line: print(line, flush=True))
+    except AssertionError as e:
+        print("FAILED:", e)
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()
