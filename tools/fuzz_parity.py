@@ -1,5 +1,5 @@
 """Random scenes and options through both closest-hit paths of the HIP library against the CPU oracle.
-usage: fuzz_parity.py [first_seed] [count]; prints one line per case and exits non-zero on the first disagreement
+usage: fuzz_parity.py [first_seed] [count] [big]; prints one line per case and exits non-zero on the first disagreement
 beyond the tolerances of tests/test_gpu_parity.py."""
 import os
 import sys
@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 
 
-def random_scene(seed):
+def random_scene(seed, big=False):
     from raytracing_amd.scene import RGB, Camera, Euler, Light, Material, Mesh, Object, Scale, Scene, Shader, Sphere, Vec3
     rng = np.random.default_rng(seed)
     s = Scene()
@@ -24,12 +24,12 @@ def random_scene(seed):
                       emissionStrength=float(0.4 if rng.random() < 0.06 else 0.0))
 
     for m in range(int(rng.integers(1, 4))):
-        n = int(rng.integers(1, 40))
+        n = int(rng.integers(200, 1500)) if big else int(rng.integers(1, 40))
         verts, faces = [], []
         centre = rng.uniform(-2.5, 2.5, 3) + [0, 0, 2]
         for k in range(n):
             c = centre + rng.uniform(-1.5, 1.5, 3)
-            e1, e2 = rng.uniform(-1.2, 1.2, 3), rng.uniform(-1.2, 1.2, 3)
+            e1, e2 = rng.uniform(-1.2, 1.2, 3) * (0.25 if big else 1.0), rng.uniform(-1.2, 1.2, 3) * (0.25 if big else 1.0)
             for p in (c, c + e1, c + e2):
                 verts.append(Vec3(*(float(v) for v in p)))
             faces.append((3 * k, 3 * k + 1, 3 * k + 2))
@@ -72,7 +72,7 @@ def check_case(out, ref, frag, opt):
         assert abs(out["stats"][k] - ref["stats"][k]) <= max(2, ref["stats"][k] // 1000), (k, out["stats"][k], ref["stats"][k])
 
 
-def run_cases(first, count, report=print):
+def run_cases(first, count, report=print, big=False):
     from oracle import oracle
     from raytracing_amd import _native
     from raytracing_amd.flatten import flatten_scene
@@ -82,7 +82,7 @@ def run_cases(first, count, report=print):
         for a, c in ctxs.items():
             c.set_accel(a)
         for seed in range(first, first + count):
-            scene, opt = random_scene(seed)
+            scene, opt = random_scene(seed, big)
             flat = flatten_scene(scene)
             ref = oracle.render(flat, opt, seed=seed)
             frag = oracle.primary_fragility(flat, opt)
@@ -109,8 +109,9 @@ def run_cases(first, count, report=print):
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"     # meshes of hundreds of small triangles: deep hierarchies
     try:
-        run_cases(first, count, report=lambda line: print(line, flush=True))
+        run_cases(first, count, report=lambda line: print(line, flush=True), big=big)
     except AssertionError as e:
         print("FAILED:", e)
         sys.exit(1)
