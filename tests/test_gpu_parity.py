@@ -712,7 +712,7 @@ def test_contexts_on_two_host_threads(gpu_ctx):
 
 
 def test_random_scenes_on_both_paths(oracle_mod):
-    """Forty-five random scenes (triangle soups with several shaders, glass, emitters, spheres, zero to many lights) with
+    """Forty-three random scenes (triangle soups with several shaders, glass, emitters, spheres, zero to many lights) with
     random sizes, bounces and samples, through the brute-force and the LBVH path against the oracle
     (tools/fuzz_parity.py, which also says what a random scene is allowed that a fixture is not)."""
     import os
@@ -721,5 +721,5 @@ def test_random_scenes_on_both_paths(oracle_mod):
     import fuzz_parity
     lines = []
     fuzz_parity.run_cases(0, 40, report=lines.append)
-    fuzz_parity.run_cases(0, 5, report=lines.append, big=True)     # meshes of hundreds of triangles: deep hierarchies, long plane lists
-    assert len(lines) == 45
+    fuzz_parity.run_cases(0, 3, report=lines.append, big=True)     # meshes of hundreds of triangles: deep hierarchies, long plane lists
+    assert len(lines) == 43
