@@ -94,6 +94,13 @@ def run_cases(first, count, report=print, big=False):
                     check_case(out, ref, frag, opt)
                     # the two paths evaluate the interior test differently (two in-plane coordinates against three):
                     # they too may part ways at an edge, by as little
+                    # any part of the frame -- a block of rows, every n-th row -- is the same pixels, exactly
+                    prng = np.random.default_rng(seed + 77)
+                    stride = int(prng.integers(1, 4))
+                    row0 = int(prng.integers(0, opt["height"]))
+                    nrows = int(prng.integers(1, (opt["height"] - row0 + stride - 1) // stride + 1))
+                    part = c.render_rows(opt, seed=seed, row0=row0, nrows=nrows, row_stride=stride)
+                    assert np.array_equal(part["bgr"], out["bgr"][row0::stride][:nrows]), ("rows", row0, nrows, stride)
                     counts[a] = out["stats"]["nodes"]
                     assert abs(counts[a] - counts["brute"]) <= max(2, counts[a] // 1000), ("the two paths disagree", counts)
                 except AssertionError as e:
