@@ -101,6 +101,15 @@ def run_cases(first, count, report=print, big=False):
                     nrows = int(prng.integers(1, (opt["height"] - row0 + stride - 1) // stride + 1))
                     part = c.render_rows(opt, seed=seed, row0=row0, nrows=nrows, row_stride=stride)
                     assert np.array_equal(part["bgr"], out["bgr"][row0::stride][:nrows]), ("rows", row0, nrows, stride)
+                    # the trees of one pixel's samples, traced one by one, carry the colours the frame averaged
+                    x, y = int(prng.integers(0, opt["width"])), int(prng.integers(0, opt["height"]))
+                    S = opt["samples"] if opt["bounces"] > 1 else 1
+                    roots = []
+                    for smp in range(S):
+                        nodes = c.trace_pixel(opt, x, y, smp, seed=seed)
+                        assert not nodes or nodes[0].heap == 1
+                        roots.append(list(nodes[0].color) if nodes else [float(v) for v in opt["ambient"]])
+                    assert np.allclose(np.mean(roots, axis=0), out["radiance"][y, x], atol=2e-3), ("pixel", x, y, roots, out["radiance"][y, x])
                     counts[a] = out["stats"]["nodes"]
                     assert abs(counts[a] - counts["brute"]) <= max(2, counts[a] // 1000), ("the two paths disagree", counts)
                 except AssertionError as e:
