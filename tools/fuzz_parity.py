@@ -111,6 +111,20 @@ def run_cases(first, count, report=print, big=False):
                         assert not nodes or nodes[0].heap == 1
                         roots.append(list(nodes[0].color) if nodes else [float(v) for v in opt["ambient"]])
                     assert np.allclose(np.mean(roots, axis=0), out["radiance"][y, x], atol=2e-3), ("pixel", x, y, roots, out["radiance"][y, x])
+                    # picking: closest hits of arbitrary rays (getFirstCollision) with the flag combinations its callers use
+                    n_rays = 24
+                    origins = prng.uniform(-2.5, 2.5, (n_rays, 3)) + [0, 0, 2]
+                    dirs = prng.normal(size=(n_rays, 3))
+                    lights_flag, cull_flag = bool(prng.integers(0, 2)), bool(prng.integers(0, 2))
+                    got = c.closest_hits(origins, dirs, lights_flag, cull_flag)
+                    bad = 0
+                    for i in range(n_rays):
+                        w = oracle.first_collision(flat, origins[i], dirs[i], lights_flag, cull_flag)
+                        same = got["obj"][i] == w["obj"] and got["face"][i] == w["face"]
+                        if same and w["obj"] >= 0:
+                            assert abs(got["t"][i] - w["t"]) <= 2e-4 * max(1.0, w["t"]) and got["direction"][i] == w["direction"], ("ray", i, got["t"][i], w["t"])
+                        bad += not same
+                    assert bad <= 1, f"{bad} of {n_rays} closest hits differ"
                     counts[a] = out["stats"]["nodes"]
                     assert abs(counts[a] - counts["brute"]) <= max(2, counts[a] // 1000), ("the two paths disagree", counts)
                 except AssertionError as e:
