@@ -1,5 +1,5 @@
 """Random scenes and options through both closest-hit paths of the HIP library against the CPU oracle.
-usage: fuzz_parity.py [first_seed] [count] [big]; prints one line per case and exits non-zero on the first disagreement
+usage: fuzz_parity.py [first_seed] [count] [big] [untimed]; prints one line per case and exits non-zero on the first disagreement
 beyond the tolerances of tests/test_gpu_parity.py."""
 import os
 import sys
@@ -73,7 +73,7 @@ def check_case(out, ref, frag, opt, n_lights=0):
         assert abs(out["stats"][k] - ref["stats"][k]) <= max(2, ref["stats"][k] // 1000) * (n_lights + 2), (k, out["stats"][k], ref["stats"][k])
 
 
-def run_cases(first, count, report=print, big=False):
+def run_cases(first, count, report=print, big=False, untimed=False):
     from oracle import oracle
     from raytracing_amd import _native
     from raytracing_amd.flatten import flatten_scene
@@ -82,6 +82,8 @@ def run_cases(first, count, report=print, big=False):
     try:
         for a, c in ctxs.items():
             c.set_accel(a)
+            if untimed:      # no per-kernel events: LBVH scenes run their shadow kernels on a stream of their own, overlapping the next level
+                c.set_timing(False)
         for seed in range(first, first + count):
             scene, opt = random_scene(seed, big)
             flat = flatten_scene(scene)
@@ -140,9 +142,10 @@ def run_cases(first, count, report=print, big=False):
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 24
-    big = len(sys.argv) > 3 and sys.argv[3] == "big"     # meshes of hundreds of small triangles: deep hierarchies
+    big = "big" in sys.argv[3:]              # meshes of hundreds of small triangles: deep hierarchies
+    untimed = "untimed" in sys.argv[3:]      # per-kernel timing off
     try:
-        run_cases(first, count, report=lambda line: print(line, flush=True), big=big)
+        run_cases(first, count, report=lambda line: print(line, flush=True), big=big, untimed=untimed)
     except AssertionError as e:
         print("FAILED:", e)
         sys.exit(1)
