@@ -712,7 +712,7 @@ def test_contexts_on_two_host_threads(gpu_ctx):
 
 
 def test_random_scenes_on_both_paths(oracle_mod):
-    """Forty-three random scenes (triangle soups with several shaders, glass, emitters, spheres, zero to many lights) with
+    """Fifty-five random scenes (triangle soups with several shaders, glass, emitters, spheres, zero to many lights) with
     random sizes, bounces and samples, through the brute-force and the LBVH path against the oracle
     (tools/fuzz_parity.py, which also says what a random scene is allowed that a fixture is not)."""
     import os
@@ -722,4 +722,7 @@ def test_random_scenes_on_both_paths(oracle_mod):
     lines = []
     fuzz_parity.run_cases(0, 40, report=lines.append)
     fuzz_parity.run_cases(0, 3, report=lines.append, big=True)     # meshes of hundreds of triangles: deep hierarchies, long plane lists
-    assert len(lines) == 43
+    # per-kernel timing off: the LBVH path's shadow kernels run on a stream of their own and overlap the next level
+    fuzz_parity.run_cases(0, 2, report=lines.append, big=True, untimed=True)
+    fuzz_parity.run_cases(40, 10, report=lines.append, untimed=True)
+    assert len(lines) == 55
