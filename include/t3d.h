@@ -15,13 +15,14 @@
 #ifndef T3D_H
 #define T3D_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define T3D_ABI_VERSION 2
+#define T3D_ABI_VERSION 3
 
 enum {
     T3D_OK = 0,
@@ -168,13 +169,44 @@ int t3d_render_rows(t3d_ctx* ctx, const t3d_opts* opts, int row0, int nrows, uin
  * Same work, outputs left in device memory owned by the caller (e.g. a torch tensor's data
  * pointer) and launched on `stream` (a hipStream_t passed as void*, NULL = the context's own
  * stream).  Does not synchronise unless `stats` is non-NULL.  Only a call with `stats` can see that a
- * trace tree outgrew the work buffers and trace the band again with larger ones; a call without leaves
- * that to the caller: t3d_last_call_stats afterwards returns T3D_E_CAPACITY (the output of that call is
- * then invalid; a call with `stats` on the same context grows the buffers for the calls after it).
+ * trace tree outgrew the work buffers and trace the band again with larger ones.  A call without `stats`
+ * cannot: its kernels raise a flag in host-visible memory instead, which stays raised until the host looks,
+ * which it does at the start of every later render / trace call on the context and in t3d_last_call_stats.
+ * Whichever comes first returns T3D_E_CAPACITY once -- for the EARLIER call, whose output is invalid -- and
+ * from then on asynchronous calls on the context start with buffers twice as large (a later call that returns
+ * T3D_OK did run).  The flag covers every band of a frame that was cut into several.
  */
 int t3d_render_rows_device(t3d_ctx* ctx, const t3d_opts* opts, int row0, int nrows,
                            uint8_t* bgr_device, float* radiance_device, int32_t* primary_device,
                            float* primary_t_device, void* stream, t3d_stats* stats);
+
+/*
+ * The same rows, started and not waited for: the kernels and the copy of the finished pixels into `bgr_pinned`
+ * are queued on the context's stream and the call returns.  `bgr_pinned` [nrows*W*3] should be page-locked
+ * host memory (t3d_host_alloc) so that the copy runs at the link's rate and really is asynchronous.
+ * t3d_last_call_stats waits for the frame, returns its counters and reports T3D_E_CAPACITY if a trace tree did
+ * not fit the work buffers (then ask again through t3d_render_rows, which grows them).  Lets a caller prepare
+ * the next thing on the host (Photon.render: flatten the scene again to see whether it changed) while the device
+ * renders.  No counterpart in the reference, whose render() blocks (T3DR.py:1086-1181).
+ */
+int t3d_render_rows_async(t3d_ctx* ctx, const t3d_opts* opts, int row0, int nrows, uint8_t* bgr_pinned);
+
+/*
+ * One frame on n contexts at once -- normally one per GPU of the node; several contexts of one device work too.
+ * Context k renders image rows k, k + n, k + 2n, ... (opts->row_stride is ignored) and one strided copy per context
+ * puts them in their places in `bgr_frame` [H*W*3]: host memory (page-locked for full speed), or, with
+ * frame_on_device != 0, device memory that every context's device can reach (hipMemcpyDeviceToDevice, peer copies
+ * over xGMI between GPUs).  opts->height must be a multiple of n -- the reference's rule for its stripe threads
+ * (T3DR.py:1111-1112) -- else T3D_E_INVALID.  Stands where Photon.render starts one thread per stripe and stacks the
+ * stripes (T3DR.py:1127-1165).  Every context must hold the same scene.  `stats` (nullable): counters summed over the
+ * contexts, times the maximum.  Errors are reported through ctxs[0].
+ */
+int t3d_render_frame_multi(t3d_ctx* const* ctxs, int n, const t3d_opts* opts, uint8_t* bgr_frame, int frame_on_device,
+                           t3d_stats* stats);
+
+/* Page-locked host memory for t3d_render_rows_async outputs (thin wrappers; no counterpart in the reference). */
+int t3d_host_alloc(size_t bytes, void** out);
+int t3d_host_free(void* p);
 
 /*
  * Trace one pixel sample and return its tree (Photon.trace + computeColor for one initial ray;
@@ -210,7 +242,8 @@ int t3d_closest_hits(t3d_ctx* ctx, int n, const float* origins, const float* dir
  * Counters and per-kernel timings of the most recent t3d_render_rows_device call (of its last band
  * if the image was split into several): synchronises that call's stream first.  Lets a caller run
  * render calls asynchronously (stats == NULL) and still read kernel durations afterwards.
- * T3D_E_CAPACITY reports that the asynchronous call overflowed its node buffers (output invalid).
+ * T3D_E_CAPACITY reports that the asynchronous call (any of its bands, or an earlier asynchronous call nobody
+ * has asked about since) overflowed its node buffers (output invalid); see t3d_render_rows_device.
  * No counterpart in the reference (its timing is time.time() around the threads, T3DR.py:1119-1161).
  */
 int t3d_last_call_stats(t3d_ctx* ctx, t3d_stats* stats);
@@ -246,6 +279,15 @@ int t3d_set_rounds(t3d_ctx* ctx, int mode);
 enum { T3D_ACCEL_AUTO = 0, T3D_ACCEL_BRUTE_FORCE = 1, T3D_ACCEL_LBVH = 2 };
 #define T3D_BRUTE_FORCE_MAX_PRIMS 256
 int t3d_set_accel(t3d_ctx* ctx, int mode);
+
+/*
+ * Cancellation: Photon.render polls cancelCallback() once per pixel and stops the stripe when it answers true
+ * (T3DR.py:1227-1237).  Here `poll(user)` is asked before every band of rows and after every tree level of a
+ * band (the stream is drained after each level while a callback is installed, so rendering with one costs the
+ * overlap of host and device); a non-zero answer makes the render call return T3D_E_CANCELLED at once with
+ * the output unfinished.  poll == NULL removes the callback.  The callback runs on the calling thread.
+ */
+int t3d_set_cancel(t3d_ctx* ctx, int (*poll)(void* user), void* user);
 
 int t3d_abi_version(void);
 

@@ -12,15 +12,21 @@ import numpy as np
 from .flatten import FlatScene, Opts, SceneDesc, Stats, make_opts
 
 LIB_PATH = os.environ.get("T3D_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libt3d_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 SYMBOLS = ("t3d_abi_version", "t3d_device_count", "t3d_create", "t3d_destroy", "t3d_last_error",
            "t3d_upload_scene", "t3d_render_rows", "t3d_render_rows_device", "t3d_trace_pixel", "t3d_trace_ray",
-           "t3d_closest_hits", "t3d_last_call_stats", "t3d_set_timing", "t3d_set_accel", "t3d_set_rounds")
+           "t3d_closest_hits", "t3d_last_call_stats", "t3d_set_timing", "t3d_set_accel", "t3d_set_rounds", "t3d_set_cancel",
+           "t3d_render_rows_async", "t3d_host_alloc", "t3d_host_free", "t3d_render_frame_multi")
 
 
 class NativeError(RuntimeError):
-    """The HIP library is missing, failed to load, or a call into it failed."""
+    """The HIP library is missing, failed to load, or a call into it failed (``code``: the T3D_E_* value)."""
+    code = None
+
+
+class Cancelled(NativeError):
+    """The cancel callback asked the render call to stop (T3D_E_CANCELLED)."""
 
 
 class Node(C.Structure):
@@ -30,6 +36,11 @@ class Node(C.Structure):
                 ("ray_start", C.c_float * 3), ("ray_dir", C.c_float * 3), ("ray_ior", C.c_float),
                 ("ray_obj", C.c_int32), ("color", C.c_float * 3)]
 
+
+CANCEL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+E_CAPACITY = -4
+E_CANCELLED = -5
 
 _lib = None
 
@@ -99,6 +110,16 @@ def load():
     lib.t3d_set_rounds.argtypes = [C.c_void_p, C.c_int]
     lib.t3d_set_accel.restype = C.c_int
     lib.t3d_set_accel.argtypes = [C.c_void_p, C.c_int]
+    lib.t3d_render_rows_async.restype = C.c_int
+    lib.t3d_render_rows_async.argtypes = [C.c_void_p, P(Opts), C.c_int, C.c_int, C.c_void_p]
+    lib.t3d_render_frame_multi.restype = C.c_int
+    lib.t3d_render_frame_multi.argtypes = [P(C.c_void_p), C.c_int, P(Opts), C.c_void_p, C.c_int, P(Stats)]
+    lib.t3d_host_alloc.restype = C.c_int
+    lib.t3d_host_alloc.argtypes = [C.c_size_t, P(C.c_void_p)]
+    lib.t3d_host_free.restype = C.c_int
+    lib.t3d_host_free.argtypes = [C.c_void_p]
+    lib.t3d_set_cancel.restype = C.c_int
+    lib.t3d_set_cancel.argtypes = [C.c_void_p, CANCEL_FN, C.c_void_p]
     if lib.t3d_abi_version() != ABI_VERSION:
         raise NativeError(f"libt3d_hip.so has ABI version {lib.t3d_abi_version()}, expected {ABI_VERSION}")
     _lib = lib
@@ -114,6 +135,47 @@ def device_count() -> int:
 
 def _ptr(a):
     return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class _PinnedBlock:
+    """One page-locked host allocation; goes back to the pool when the last array that views it is collected."""
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        if load().t3d_host_alloc(nbytes, C.byref(p)) != 0:
+            raise NativeError(f"t3d_host_alloc({nbytes}) failed")
+        self.ptr, self.nbytes = p.value, nbytes
+        self.buffer = (C.c_uint8 * nbytes).from_address(self.ptr)
+
+    def free(self):
+        if self.ptr:
+            load().t3d_host_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+
+_pinned_pool = {}     # nbytes -> [free blocks]
+_PINNED_KEEP = 4      # free blocks kept per size; more are released
+
+
+def pinned_image(shape):
+    """A uint8 array of ``shape`` in page-locked host memory (the device copies into it at the link's rate, and
+    asynchronously).  The memory returns to a small pool when the array and every view of it are gone."""
+    import weakref
+    nbytes = int(np.prod(shape))
+    free = _pinned_pool.setdefault(nbytes, [])
+    block = free.pop() if free else _PinnedBlock(nbytes)
+    root = np.frombuffer(block.buffer, dtype=np.uint8, count=nbytes)
+
+    def give_back(b=block, n=nbytes):
+        lst = _pinned_pool.setdefault(n, [])
+        if len(lst) < _PINNED_KEEP:
+            lst.append(b)
+        else:
+            b.free()
+    # every view (the reshaped array returned here, a channel flip of it, ...) keeps `root` alive, so `root` dies
+    # last: that is when the block is free again
+    weakref.finalize(root, give_back)
+    return root.reshape(shape)
 
 
 class Context:
@@ -145,7 +207,9 @@ class Context:
 
     def _check(self, rc, what):
         if rc < 0:
-            raise NativeError(f"{what} failed ({rc}): {self._lib.t3d_last_error(self._h).decode()}")
+            err = (Cancelled if rc == E_CANCELLED else NativeError)(f"{what} failed ({rc}): {self._lib.t3d_last_error(self._h).decode()}")
+            err.code = rc
+            raise err
         return rc
 
     def upload(self, flat: FlatScene):
@@ -174,6 +238,14 @@ class Context:
                                               _ptr(prim_t), C.byref(stats)), "t3d_render_rows")
         return dict(bgr=bgr, radiance=rad, prim=prim, prim_t=prim_t, stats=stats.as_dict())
 
+    def render_rows_async(self, options: dict, seed: int, row0: int, nrows: int, out, row_stride: int = 1):
+        """Start rendering into ``out`` (a ``pinned_image`` of shape [nrows, W, 3]) and return at once;
+        ``last_call_stats()`` waits for the frame and returns its counters."""
+        opts = make_opts(options, seed, row_stride=row_stride)
+        if out.dtype != np.uint8 or out.shape != (nrows, opts.width, 3) or not out.flags.c_contiguous:
+            raise ValueError(f"out must be a C-contiguous uint8 array of shape {(nrows, opts.width, 3)}")
+        self._check(self._lib.t3d_render_rows_async(self._h, C.byref(opts), row0, nrows, _ptr(out)), "t3d_render_rows_async")
+
     def render_rows_device(self, options: dict, seed: int, row0: int, nrows: int, bgr_ptr: int, radiance_ptr: int = 0,
                            primary_ptr: int = 0, primary_t_ptr: int = 0, stream: int = 0, want_stats=True,
                            row_stride: int = 1):
@@ -200,6 +272,20 @@ class Context:
     def set_full_rounds(self, full: bool):
         """Always 128 rays per trace round (for callers that keep several bands in flight) instead of the adaptive cut."""
         self._check(self._lib.t3d_set_rounds(self._h, 1 if full else 0), "t3d_set_rounds")
+
+    def set_cancel(self, poll):
+        """``poll()`` -> truthy to stop: asked before every band and after every tree level of a render call, which then
+        raises ``Cancelled``.  ``None`` removes the callback.  An exception inside ``poll`` counts as "stop"."""
+        if poll is None:
+            self._cancel_fn = CANCEL_FN()
+        else:
+            def trampoline(_user):
+                try:
+                    return 1 if poll() else 0
+                except Exception:
+                    return 1
+            self._cancel_fn = CANCEL_FN(trampoline)    # kept alive for as long as the library may call it
+        self._check(self._lib.t3d_set_cancel(self._h, self._cancel_fn, None), "t3d_set_cancel")
 
     def set_timing(self, per_kernel: bool):
         """Per-kernel event timing on/off (on: ms_k_level / ms_resolve filled, a few us of idle per launch)."""
@@ -233,3 +319,23 @@ class Context:
         self._check(self._lib.t3d_closest_hits(self._h, n, _ptr(o), _ptr(d), int(lights), int(back_cull), _ptr(obj),
                                                _ptr(face), _ptr(t), _ptr(dirflag), _ptr(normal)), "t3d_closest_hits")
         return dict(obj=obj, face=face, t=t, direction=dirflag, normal=normal)
+
+
+def render_frame_multi(contexts, options: dict, seed: int, out=None, frame_ptr: int = 0):
+    """One frame on several contexts (normally one per GPU), rows interleaved: context k renders rows k, k + n, ...
+    Every context must hold the same scene.  ``out``: uint8 [H, W, 3] host array (``pinned_image`` for full speed);
+    or ``frame_ptr``: address of a device buffer of that size.  -> stats dict (counters summed over the contexts)."""
+    lib = load()
+    n = len(contexts)
+    opts = make_opts(options, seed)
+    if out is not None:
+        if out.dtype != np.uint8 or out.shape != (opts.height, opts.width, 3) or not out.flags.c_contiguous:
+            raise ValueError(f"out must be a C-contiguous uint8 array of shape {(opts.height, opts.width, 3)}")
+    elif not frame_ptr:
+        raise ValueError("give a host array or a device address")
+    handles = (C.c_void_p * n)(*[c._h for c in contexts])
+    stats = Stats()
+    rc = lib.t3d_render_frame_multi(handles, n, C.byref(opts), _ptr(out) if out is not None else C.c_void_p(frame_ptr),
+                                    0 if out is not None else 1, C.byref(stats))
+    contexts[0]._check(rc, "t3d_render_frame_multi")
+    return stats.as_dict()

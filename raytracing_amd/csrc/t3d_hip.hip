@@ -46,6 +46,7 @@
 #include <cmath>
 #include <map>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -136,6 +137,9 @@ struct RenderParams {
     int tiled;              // level 0 walks the band in 16 x 8 pixel tiles (width % 16 == 0, rows % 8 == 0)
     float ray_o[3], ray_d[3], ray_ior;  // single == 2: the initial ray (unit direction) ...
     int ray_obj;                        // ... and the object it travels inside (-1 none)
+    int shard_bits;  // log2 of the number of queue shards in use: 6 for image bands, 0 for the tree of a single ray
+    int* sticky;     // two host-visible words (pinned memory): [0] set when a queue or node array overflows, [1] when a
+                     // traversal stack does; see t3d_ctx
 };
 
 // One queued ray (64 B).
@@ -446,7 +450,7 @@ __device__ __forceinline__ void bvh_begin(BvhLane& s, V3 o, V3 d, bool lights, b
 // (one triangle or sphere).  Returns true when nothing is left on the stack.
 // lds: this lane's column of the wave's LDS stack (entry e at lds[64 e]); deep: entries beyond it
 __device__ __forceinline__ bool bvh_step(const DevScene& sc, BvhLane& s, int* lds, int (&deep)[T3D_BVH_DEEP_STACK], BvhCount& bc,
-                                         int* stack_overflow) {
+                                         int* stack_overflow, int* sticky) {
     const V3 o = s.o, d = s.d, inv = s.inv, oi = s.oi;
     auto pop = [&]() {
         if (s.sp == 0) { s.node = BVH_DONE; return; }
@@ -505,7 +509,7 @@ __device__ __forceinline__ bool bvh_step(const DevScene& sc, BvhLane& s, int* ld
                 if (tn[k] < __builtin_inff()) {
                     if (s.sp < T3D_BVH_LDS_STACK) { s.top = ln[k]; lds[64 * s.sp++] = s.top; }
                     else if (s.sp < T3D_BVH_STACK) { s.top = ln[k]; deep[s.sp++ - T3D_BVH_LDS_STACK] = s.top; bc.deep++; }
-                    else *stack_overflow = 1;
+                    else { *stack_overflow = 1; if (sticky) sticky[1] = 1; }
                 }
             }
         }
@@ -574,7 +578,7 @@ __device__ __forceinline__ void bvh_closest(const DevScene& sc, const DevSphere*
     BvhLane s;
     int deep[T3D_BVH_DEEP_STACK];
     bvh_begin(s, o, d, lights, back_cull);
-    while (!bvh_step(sc, s, lds, deep, bc, stack_overflow)) {}
+    while (!bvh_step(sc, s, lds, deep, bc, stack_overflow, nullptr)) {}
     out.t = s.best; out.prim = s.prim; out.back = s.back;
 }
 
@@ -595,7 +599,9 @@ struct TraceOut {
 __device__ __forceinline__ void store_pixel(uint8_t* __restrict__ bgr, float* __restrict__ radiance, int p, float r, float g, float b, float n) {
     const float inv = 1.0f / n;
     if (radiance) { radiance[3 * p] = r * inv; radiance[3 * p + 1] = g * inv; radiance[3 * p + 2] = b * inv; }
-    const float fr = fminf(floorf(r / n), 255.0f), fg = fminf(floorf(g / n), 255.0f), fb = fminf(floorf(b / n), 255.0f);
+    // fmaxf also turns NaN into 0: the conversion to uint8 is only defined for values in range (negative colours or
+    // strengths can make a sum negative; the reference would wrap such a value when it stores it into its uint8 array)
+    const float fr = fmaxf(fminf(floorf(r / n), 255.0f), 0.0f), fg = fmaxf(fminf(floorf(g / n), 255.0f), 0.0f), fb = fmaxf(fminf(floorf(b / n), 255.0f), 0.0f);
     bgr[3 * p] = (uint8_t)fb; bgr[3 * p + 1] = (uint8_t)fg; bgr[3 * p + 2] = (uint8_t)fr;
 }
 
@@ -815,7 +821,7 @@ __device__ __forceinline__ void process_ray(const DevScene& sc, const DevSphere*
     const int bloc = base_r + c_t + __popcll(m_b & wc.lt_mask);
     const int node = wc.shard * wc.shard_cap + nloc;                  // index within the level
     const bool stored = shaded && nloc < wc.shard_cap;
-    if (shaded && !stored) cnt->overflow = 1;
+    if (shaded && !stored) { cnt->overflow = 1; rp.sticky[0] = 1; }
     if (stored) {
         const float k = 2.0f / 255.0f;  // absent children count as ambient * 2/255 (T3DR.py:1054-1055)
         const size_t g = wc.node_base + (size_t)node;
@@ -832,7 +838,7 @@ __device__ __forceinline__ void process_ray(const DevScene& sc, const DevSphere*
             r.p = make_float4(o.x, o.y, o.z, __int_as_float((int)(wc.node_base + node)));
             r.k = make_uint4(in.ps, child_heap + 1u, 1u, in.pixel_hash);
             rays_out[wc.shard * wc.shard_cap + tloc] = r;
-        } else cnt->overflow = 1;
+        } else { cnt->overflow = 1; rp.sticky[0] = 1; }
     }
     if (want_b && stored) {
         if (bloc < wc.shard_cap) {
@@ -842,7 +848,7 @@ __device__ __forceinline__ void process_ray(const DevScene& sc, const DevSphere*
             r.p = make_float4(o.x, o.y, o.z, __int_as_float((int)(wc.node_base + node)));
             r.k = make_uint4(in.ps, child_heap, 0u, in.pixel_hash);
             rays_out[wc.shard * wc.shard_cap + bloc] = r;
-        } else cnt->overflow = 1;
+        } else { cnt->overflow = 1; rp.sticky[0] = 1; }
     }
     if constexpr (RING > 0) {
         // shaded nodes enter the wave's ring in lane order
@@ -931,8 +937,8 @@ __global__ __launch_bounds__(T3D_BLOCK, 4) void k_level(DevScene sc, GEO_PARAMS,
     wc.lt_mask = (1ull << wc.lane) - 1ull;
     const int gw = blockIdx.x * T3D_WAVES + wc.wid;  // global wave id
     const int nw = gridDim.x * T3D_WAVES;            // multiple of T3D_SHARDS (host guarantees)
-    wc.shard = gw % T3D_SHARDS;
-    wc.shard_cap = rp.cap / T3D_SHARDS;
+    wc.shard = gw & ((1 << rp.shard_bits) - 1);
+    wc.shard_cap = rp.cap >> rp.shard_bits;
     wc.level = level;
     wc.node_base = (size_t)level * rp.cap;
     wc.L = sc.n_lights;
@@ -942,15 +948,15 @@ __global__ __launch_bounds__(T3D_BLOCK, 4) void k_level(DevScene sc, GEO_PARAMS,
     // input: level 0 is the dense list of primary samples; deeper levels read this wave's shard of the queue
     const int n_in = LEVEL0 ? rp.n0 : min(cnt->n_rays[level][wc.shard].v, wc.shard_cap);
     const int queue_base = wc.shard * wc.shard_cap;
-    int chunk = LEVEL0 ? gw : gw / T3D_SHARDS;  // in units of cs rays
-    const int chunk_step = LEVEL0 ? nw : nw / T3D_SHARDS;
+    int chunk = LEVEL0 ? gw : gw >> rp.shard_bits;  // in units of cs rays
+    const int chunk_step = LEVEL0 ? nw : nw >> rp.shard_bits;
     // Rays per trace round.  A launch with little work (a thin band of rows, one rank's share of a frame) is
     // bound by the number of rounds one wave runs back to back -- a trace round and the shadow rounds of the
     // nodes it creates -- not by throughput: such a launch is cut into more, smaller chunks (64 or 32 rays,
     // one per lane) as long as every chunk still finds a resident wave.  A caller that keeps several bands in flight on
     // several contexts hides that latency itself and asks for full rounds, which waste no slots (t3d_set_rounds).
     const int resident_all = nw < rp.resident_waves ? nw : rp.resident_waves;
-    const int resident = LEVEL0 ? resident_all : resident_all / T3D_SHARDS;
+    const int resident = LEVEL0 ? resident_all : resident_all >> rp.shard_bits;
     const int cs = rp.full_rounds || n_in > 64 * resident ? 128 : (n_in > 32 * resident ? 64 : 32);
     int ring_nodes = 0;  // nodes appended to the ring so far      (wave-uniform)
     int items_done = 0;  // (node, light) pairs already traced     (wave-uniform)
@@ -1025,12 +1031,12 @@ struct RayFeed {
 // Takes the next chunk when the current one is used up.  Called by all 64 lanes.  Lists of level 0 are not sharded:
 // there shard s owns chunks s, s + 64, ... of the one list (INTERLEAVED).
 template <bool INTERLEAVED>
-__device__ __forceinline__ void feed_refresh(RayFeed& f, PaddedCount* counter, int lane, int shard, long long n_in) {
+__device__ __forceinline__ void feed_refresh(RayFeed& f, PaddedCount* counter, int lane, int shard, int shard_bits, long long n_in) {
     if (f.pos < f.end || f.exhausted) return;
     int j = 0;
     if (lane == 0) j = atomicAdd(&counter->v, 1);
     j = __builtin_amdgcn_readfirstlane(j);
-    const long long base = (INTERLEAVED ? (long long)j * T3D_SHARDS + shard : (long long)j) * 64;
+    const long long base = (INTERLEAVED ? ((long long)j << shard_bits) + shard : (long long)j) * 64;
     if (base >= n_in) f.exhausted = true;
     else { f.pos = base; f.end = base + 64 < n_in ? base + 64 : n_in; }
 }
@@ -1056,8 +1062,8 @@ __global__ __launch_bounds__(T3D_BLOCK, T3D_BVH_WAVES) void k_bvh_trace(DevScene
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int gw = blockIdx.x * T3D_WAVES + (threadIdx.x >> 6);
-    const int shard = gw % T3D_SHARDS;   // the grid holds a multiple of T3D_SHARDS waves (host guarantees)
-    const int shard_cap = rp.cap / T3D_SHARDS;
+    const int shard = gw & ((1 << rp.shard_bits) - 1);   // the grid holds a multiple of that many waves (host guarantees)
+    const int shard_cap = rp.cap >> rp.shard_bits;
     const int n_in = LEVEL0 ? rp.n0 : min(cnt->n_rays[level][shard].v, shard_cap);
     const int queue_base = shard * shard_cap;
     const bool lights = LEVEL0 ? (rp.lights != 0) : true;
@@ -1079,7 +1085,7 @@ __global__ __launch_bounds__(T3D_BLOCK, T3D_BVH_WAVES) void k_bvh_trace(DevScene
                 hits[mine] = make_uint2(__float_as_uint(st.best) | ((uint32_t)st.back << 31), (uint32_t)st.prim);
                 pending = false;
             }
-            feed_refresh<LEVEL0>(feed, &fetch[shard], lane, shard, n_in);
+            feed_refresh<LEVEL0>(feed, &fetch[shard], lane, shard, rp.shard_bits, n_in);
             if (feed.exhausted && n_idle == 64) break;  // nothing in flight and nothing left to hand out
             const long long idx = feed.pos + __popcll(idle & lt_mask);
             if (!have && idx < feed.end) {
@@ -1091,7 +1097,7 @@ __global__ __launch_bounds__(T3D_BLOCK, T3D_BVH_WAVES) void k_bvh_trace(DevScene
             }
             feed.pos = feed.pos + n_idle < feed.end ? feed.pos + n_idle : feed.end;
         }
-        if (have && bvh_step(sc, st, lds, deep, bc, &cnt->bvh_stack_overflow)) { have = false; pending = true; }
+        if (have && bvh_step(sc, st, lds, deep, bc, &cnt->bvh_stack_overflow, rp.sticky)) { have = false; pending = true; }
     }
     bvh_stats_flush(bc, cnt, lane, shard);
 }
@@ -1106,16 +1112,16 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_bvh_process(DevScene sc, const De
     wc.lt_mask = (1ull << wc.lane) - 1ull;
     const int gw = blockIdx.x * T3D_WAVES + wc.wid;
     const int nw = gridDim.x * T3D_WAVES;
-    wc.shard = gw % T3D_SHARDS;
-    wc.shard_cap = rp.cap / T3D_SHARDS;
+    wc.shard = gw & ((1 << rp.shard_bits) - 1);
+    wc.shard_cap = rp.cap >> rp.shard_bits;
     wc.level = level;
     wc.node_base = (size_t)level * rp.cap;
     wc.L = sc.n_lights;
     const int n_in = LEVEL0 ? rp.n0 : min(cnt->n_rays[level][wc.shard].v, wc.shard_cap);
     const int queue_base = wc.shard * wc.shard_cap;
-    const int chunk_step = LEVEL0 ? nw : nw / T3D_SHARDS;
+    const int chunk_step = LEVEL0 ? nw : nw >> rp.shard_bits;
     int unused = 0;
-    for (int chunk = LEVEL0 ? gw : gw / T3D_SHARDS; (long long)chunk * 64 < n_in; chunk += chunk_step) {
+    for (int chunk = LEVEL0 ? gw : gw >> rp.shard_bits; (long long)chunk * 64 < n_in; chunk += chunk_step) {
         RayIn in;
         load_ray<LEVEL0>(sc, rp, rays_in, chunk * 64 + wc.lane, n_in, queue_base, in);
         Hit h;
@@ -1135,8 +1141,8 @@ __global__ __launch_bounds__(T3D_BLOCK, T3D_BVH_WAVES) void k_bvh_shadow(DevScen
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int gw = blockIdx.x * T3D_WAVES + (threadIdx.x >> 6);
-    const int shard = gw % T3D_SHARDS;
-    const int shard_cap = rp.cap / T3D_SHARDS;
+    const int shard = gw & ((1 << rp.shard_bits) - 1);
+    const int shard_cap = rp.cap >> rp.shard_bits;
     const int L = sc.n_lights;
     const long long n_in = (long long)min(cnt->n_nodes[level][shard].v, shard_cap) * L;  // (node, light) pairs of this shard
     const size_t node_base = (size_t)level * rp.cap;
@@ -1160,7 +1166,7 @@ __global__ __launch_bounds__(T3D_BLOCK, T3D_BVH_WAVES) void k_bvh_shadow(DevScen
                 pool.li[(node_base + (size_t)my_node) * L + my_light] = shadow_intensity(sc, spheres, s, h);
                 pending = false;
             }
-            feed_refresh<false>(feed, &fetch[shard], lane, shard, n_in);
+            feed_refresh<false>(feed, &fetch[shard], lane, shard, rp.shard_bits, n_in);
             if (feed.exhausted && n_idle == 64) break;
             const long long idx = feed.pos + __popcll(idle & lt_mask);
             if (!have && idx < feed.end) {
@@ -1173,7 +1179,7 @@ __global__ __launch_bounds__(T3D_BLOCK, T3D_BVH_WAVES) void k_bvh_shadow(DevScen
             }
             feed.pos = feed.pos + n_idle < feed.end ? feed.pos + n_idle : feed.end;
         }
-        if (have && bvh_step(sc, st, lds, deep, bc, &cnt->bvh_stack_overflow)) { have = false; pending = true; }
+        if (have && bvh_step(sc, st, lds, deep, bc, &cnt->bvh_stack_overflow, rp.sticky)) { have = false; pending = true; }
     }
     bvh_stats_flush(bc, cnt, lane, shard);
 }
@@ -1189,12 +1195,12 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_resolve(DevScene sc, RenderParams
     if (level == 0)
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_zero; i += gridDim.x * blockDim.x) zero[i] = make_uint4(0u, 0u, 0u, 0u);
     const size_t node_base = (size_t)level * rp.cap;
-    const int shard_cap = rp.cap / T3D_SHARDS;
+    const int shard_cap = rp.cap >> rp.shard_bits;
     const int lane = threadIdx.x & 63;
-    const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;  // nw: multiple of T3D_SHARDS
-    const int shard = gw % T3D_SHARDS;
+    const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;  // nw: multiple of the shard count
+    const int shard = gw & ((1 << rp.shard_bits) - 1);
     const int n = min(cnt->n_nodes[level][shard].v, shard_cap);
-    for (int k = (gw / T3D_SHARDS) * 64 + lane; k < n; k += (nw / T3D_SHARDS) * 64) {
+    for (int k = (gw >> rp.shard_bits) * 64 + lane; k < n; k += (nw >> rp.shard_bits) * 64) {
         const size_t g = node_base + (size_t)shard * shard_cap + (size_t)k;
         const float4 c = pool.c[g], d = pool.d[g];
         const int meta = __float_as_int(d.w);
@@ -1287,6 +1293,21 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_closest(DevScene sc, GEO_PARAMS, 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// Work buffers of one render call (a band of rows, or the tree of a single ray).
+struct Work {
+    size_t cap = 0;      // entries per level in the ray queues and node arrays
+    int levels = 0;
+    int li_lights = 0;   // lights the li array was sized for
+    RayRec* rays[2] = {nullptr, nullptr};
+    NodePool pool{};
+    // LBVH path only: closest hit of every ray of the current level; shading inputs of its new nodes
+    uint2* hits = nullptr;
+    float4* src_a[2] = {nullptr, nullptr}; float4* src_b[2] = {nullptr, nullptr};  // by level parity: see render_band
+    size_t n0 = 0;       // primary samples sample_color holds
+    float4* sample_color = nullptr;
+    uint64_t gen = 0;    // counts (re)allocations: a launch graph holds the addresses
+};
+
 struct t3d_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -1303,18 +1324,12 @@ struct t3d_ctx {
     void* d_tri_meta = nullptr; void* d_spheres = nullptr; void* d_lights = nullptr;
     void* d_shaders = nullptr; void* d_obj_ior = nullptr;
     int n_objects = 0, n_sphere_objs = 0, n_light_objs = 0;
-    // work buffers
-    size_t cap_alloc = 0; int levels_alloc = 0; int li_lights = 0;
-    RayRec* d_rays[2] = {nullptr, nullptr};
-    NodePool pool{};
-    // LBVH path only: closest hit of every ray of the current level; shading inputs of its new nodes
-    uint2* d_hits = nullptr;
-    float4* d_src_a[2] = {nullptr, nullptr}; float4* d_src_b[2] = {nullptr, nullptr};  // by level parity: see render_band
+    // work buffers: one set for image bands, a small one for the tree of a single ray (t3d_trace_pixel / t3d_trace_ray), so
+    // that a picked pixel neither frees the band buffers nor invalidates the launch graphs that hold their addresses
+    Work work, single_work;
     hipStream_t shadow_stream = nullptr;             // k_bvh_shadow of level d runs beside the tracing of level d + 1
     hipEvent_t ev_traced[T3D_MAX_BOUNCES + 2] = {};  // level d classified: its shadow rays may start
     hipEvent_t ev_shadowed[T3D_MAX_BOUNCES + 2] = {};  // shadow rays of level d done
-    size_t n0_alloc = 0;
-    float4* d_sample_color = nullptr;
     Counters* d_cnt = nullptr;            // counters of the current / most recent band: one of the pair
     Counters* d_cnt_pair[2] = {nullptr, nullptr};
     int cnt_idx = 0;                      // d_cnt_pair[cnt_idx] is all zero between bands ...
@@ -1342,7 +1357,20 @@ struct t3d_ctx {
     bool graphs_enabled = true;
     bool full_rounds = false;       // t3d_set_rounds
     uint64_t scene_gen = 0;         // counts uploads
-    uint64_t work_gen = 0;          // counts (re)allocations of the work buffers: a graph holds their addresses
+    // Overflow that nobody was waiting for.  An asynchronous render call (no stats) returns before its kernels have run, so
+    // a trace tree that outgrows the queues or node arrays cannot be reported by that call.  The kernels raise these two
+    // words in pinned host memory ([0] capacity, [1] traversal stack) besides the per-band counters; they stay raised until
+    // the host looks: at the start of the next render call on the context and in t3d_last_call_stats, either of which then
+    // returns T3D_E_CAPACITY for the earlier call (whose output is invalid) and lets later asynchronous calls start with
+    // larger buffers.  Kernels only ever write there on an overflow.
+    int* h_sticky = nullptr;
+    size_t async_min_cap = 0;       // entries per level that asynchronous calls start with: twice what the last one that overflowed had
+    size_t last_async_cap = 0;      // entries per level of the most recent asynchronous band
+    // cancellation (Photon.render's cancelCallback, T3DR.py:1227-1237)
+    int (*cancel_cb)(void*) = nullptr; void* cancel_user = nullptr;
+    // t3d_closest_hits: pinned staging the kernel reads its rays from and writes its answers to
+    void* h_pick = nullptr; size_t pick_alloc = 0;
+    t3d_node* d_dbg = nullptr; int dbg_alloc = 0;   // node records of a single ray's tree (t3d_trace_pixel / t3d_trace_ray)
     bool counters_on_host = false;   // h_cnt holds (or is about to receive) the counters of the most recent band
 };
 
@@ -1367,6 +1395,8 @@ extern "C" int t3d_device_count(void) {
 
 extern "C" const char* t3d_last_error(const t3d_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
+extern "C" void t3d_destroy(t3d_ctx* c);
+
 extern "C" int t3d_create(int device, t3d_ctx** out) {
     if (!out) return T3D_E_INVALID;
     *out = nullptr;
@@ -1376,15 +1406,14 @@ extern "C" int t3d_create(int device, t3d_ctx** out) {
     if (device < 0 || device >= n) { g_create_err = "device index out of range"; return T3D_E_INVALID; }
     t3d_ctx* c = new t3d_ctx();
     c->device = device;
-    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
-        g_create_err = std::string("t3d_create: ") + hipGetErrorString(e);
-        delete c;
-        return T3D_E_DEVICE;
-    }
-    for (auto& ev : c->ev) hipEventCreate(&ev);
-    for (auto& ev : c->ev_traced) hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-    for (auto& ev : c->ev_shadowed) hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-    hipStreamCreateWithFlags(&c->shadow_stream, hipStreamNonBlocking);
+    // every failure below goes through t3d_destroy, which releases whatever exists by then (all handles start out null)
+    auto fail = [&](int code, const std::string& what) { g_create_err = "t3d_create: " + what; t3d_destroy(c); return code; };
+    if ((e = hipSetDevice(device)) != hipSuccess) return fail(T3D_E_DEVICE, hipGetErrorString(e));
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail(T3D_E_DEVICE, hipGetErrorString(e));
+    if ((e = hipStreamCreateWithFlags(&c->shadow_stream, hipStreamNonBlocking)) != hipSuccess) return fail(T3D_E_DEVICE, hipGetErrorString(e));
+    for (auto& ev : c->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(T3D_E_DEVICE, hipGetErrorString(e));
+    for (auto& ev : c->ev_traced) if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return fail(T3D_E_DEVICE, hipGetErrorString(e));
+    for (auto& ev : c->ev_shadowed) if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return fail(T3D_E_DEVICE, hipGetErrorString(e));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_sm = prop.multiProcessorCount;
     if (getenv("T3D_NO_GRAPHS")) c->graphs_enabled = false;
@@ -1393,11 +1422,10 @@ extern "C" int t3d_create(int device, t3d_ctx** out) {
     if (hipMalloc((void**)&c->d_cnt_pair[0], sizeof(Counters)) != hipSuccess || hipMalloc((void**)&c->d_cnt_pair[1], sizeof(Counters)) != hipSuccess ||
         hipMemset(c->d_cnt_pair[0], 0, sizeof(Counters)) != hipSuccess || hipMemset(c->d_cnt_pair[1], 0, sizeof(Counters)) != hipSuccess ||
         hipMalloc((void**)&c->d_fetch, sizeof(PaddedCount) * (T3D_MAX_BOUNCES + 2) * 2 * T3D_SHARDS) != hipSuccess ||
-        hipHostMalloc((void**)&c->h_cnt, sizeof(Counters), hipHostMallocDefault) != hipSuccess) {
-        g_create_err = "t3d_create: counter allocation failed";
-        delete c;
-        return T3D_E_NOMEM;
-    }
+        hipHostMalloc((void**)&c->h_cnt, sizeof(Counters), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_sticky, 64, hipHostMallocDefault) != hipSuccess)
+        return fail(T3D_E_NOMEM, "counter allocation failed");
+    c->h_sticky[0] = c->h_sticky[1] = 0;
     *out = c;
     return T3D_OK;
 }
@@ -1411,29 +1439,35 @@ static void free_scene(t3d_ctx* c) {
     c->d_tri_meta = c->d_spheres = c->d_lights = c->d_shaders = c->d_obj_ior = nullptr;
     c->has_scene = false;
 }
-static void free_work(t3d_ctx* c) {
-    c->work_gen++;
-    hipFree(c->d_rays[0]); hipFree(c->d_rays[1]); hipFree(c->pool.parent); hipFree(c->pool.c);
-    hipFree(c->pool.d); hipFree(c->pool.dbg); hipFree(c->pool.li);
-    hipFree(c->d_hits);
-    c->d_hits = nullptr;
-    for (int k = 0; k < 2; ++k) { hipFree(c->d_src_a[k]); hipFree(c->d_src_b[k]); c->d_src_a[k] = c->d_src_b[k] = nullptr; }
-    c->d_rays[0] = c->d_rays[1] = nullptr; c->pool = NodePool{}; c->cap_alloc = 0; c->levels_alloc = 0;
+static void free_work(Work& w) {
+    const uint64_t gen = w.gen + 1;
+    hipFree(w.rays[0]); hipFree(w.rays[1]); hipFree(w.pool.parent); hipFree(w.pool.c);
+    hipFree(w.pool.d); hipFree(w.pool.dbg); hipFree(w.pool.li);
+    hipFree(w.hits);
+    for (int k = 0; k < 2; ++k) { hipFree(w.src_a[k]); hipFree(w.src_b[k]); }
+    hipFree(w.sample_color);
+    w = Work{};
+    w.gen = gen;
 }
 
 extern "C" void t3d_destroy(t3d_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    free_scene(c); free_work(c);
-    hipFree(c->d_sample_color); hipFree(c->d_cnt_pair[0]); hipFree(c->d_cnt_pair[1]); hipFree(c->d_fetch); hipHostFree(c->h_cnt);
+    if (c->shadow_stream) hipStreamSynchronize(c->shadow_stream);
+    free_scene(c); free_work(c->work); free_work(c->single_work);
+    if (c->h_sticky) hipHostFree(c->h_sticky);
+    if (c->h_pick) hipHostFree(c->h_pick);
+    hipFree(c->d_dbg);
+    hipFree(c->d_cnt_pair[0]); hipFree(c->d_cnt_pair[1]); hipFree(c->d_fetch);
+    if (c->h_cnt) hipHostFree(c->h_cnt);
     for (auto& g : c->graphs) if (g.valid) { hipGraphExecDestroy(g.exec); hipGraphDestroy(g.graph); }
     hipFree(c->d_bgr); hipFree(c->d_rad); hipFree(c->d_prim); hipFree(c->d_prim_t);
     if (c->h_stage) hipHostFree(c->h_stage);
     for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
     for (auto& ev : c->ev_traced) if (ev) hipEventDestroy(ev);
     for (auto& ev : c->ev_shadowed) if (ev) hipEventDestroy(ev);
-    if (c->shadow_stream) { hipStreamSynchronize(c->shadow_stream); hipStreamDestroy(c->shadow_stream); }
+    if (c->shadow_stream) hipStreamDestroy(c->shadow_stream);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1451,13 +1485,27 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
     if (!s || s->n_objects < 0 || s->n_tris < 0 || s->n_shaders < 0 || s->n_lights < 0) { c->err = "t3d_upload_scene: bad description"; return T3D_E_INVALID; }
     if (s->n_lights > T3D_MAX_LIGHTS) { c->err = "t3d_upload_scene: too many lights (limit 4096)"; return T3D_E_CAPACITY; }
     {
+        // an array that the counts say has entries must exist
+        const char* missing = s->n_objects > 0 && (!s->obj_type || !s->obj_tri_begin || !s->obj_tri_count || !s->obj_center || !s->obj_radius ||
+                                                   !s->obj_ior || !s->obj_strength || !s->obj_shader0) ? "an object array"
+                            : s->n_tris > 0 && (!s->tri_verts || !s->tri_shader) ? "a triangle array"
+                            : s->n_shaders > 0 && (!s->shader_color || !s->shader_rough || !s->shader_refl || !s->shader_emis) ? "a shader array"
+                            : s->n_lights > 0 && (!s->light_pos || !s->light_strength || !s->light_color) ? "a light array" : nullptr;
+        if (missing) { c->err = std::string("t3d_upload_scene: ") + missing + " is null"; return T3D_E_INVALID; }
+    }
+    {
         // geometry that is not a finite number has no place in a hierarchy or a plane group: refuse it by name
         auto finite = [](const double* p, size_t n) { if (p) for (size_t i = 0; i < n; ++i) if (!std::isfinite(p[i])) return false; return true; };
         const char* bad = !finite(s->tri_verts, (size_t)s->n_tris * 9) ? "a triangle corner"
                         : !finite(s->obj_center, (size_t)s->n_objects * 3) ? "an object position"
                         : !finite(s->obj_radius, (size_t)s->n_objects) ? "an object radius"
                         : !finite(s->light_pos, (size_t)s->n_lights * 3) ? "a light position"
-                        : !finite(s->cam_pos, 3) || !finite(s->cam_euler, 3) || !finite(&s->cam_zlen, 1) ? "the camera" : nullptr;
+                        : !finite(s->cam_pos, 3) || !finite(s->cam_euler, 3) || !finite(&s->cam_zlen, 1) ? "the camera"
+                        : !finite(s->obj_ior, (size_t)s->n_objects) || !finite(s->obj_strength, (size_t)s->n_objects) ? "an object's ior or strength"
+                        : !finite(s->shader_color, (size_t)s->n_shaders * 3) || !finite(s->shader_rough, (size_t)s->n_shaders) ||
+                          !finite(s->shader_refl, (size_t)s->n_shaders) || !finite(s->shader_emis, (size_t)s->n_shaders) ? "a shader value"
+                        : !finite(s->light_strength, (size_t)s->n_lights) || !finite(s->light_color, (size_t)s->n_lights * 3) ? "a light's strength or colour"
+                        : nullptr;
         if (bad) { c->err = std::string("t3d_upload_scene: ") + bad + " is not finite"; return T3D_E_INVALID; }
     }
     HIPCHK(c, hipSetDevice(c->device));
@@ -1708,33 +1756,36 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
     return T3D_OK;
 }
 
-static int ensure_work(t3d_ctx* c, size_t cap, int levels, size_t n0, bool dbg) {
-    if (cap > c->cap_alloc || levels > c->levels_alloc || (dbg && !c->pool.dbg) || c->sc.n_lights > c->li_lights ||
-        (c->use_bvh && !c->d_hits)) {
-        free_work(c);
+static int ensure_work(t3d_ctx* c, Work& w, size_t cap, int levels, size_t n0, bool dbg) {
+    if (cap > w.cap || levels > w.levels || (dbg && !w.pool.dbg) || c->sc.n_lights > w.li_lights || (c->use_bvh && !w.hits)) {
+        const size_t keep_n0 = w.n0;
+        float4* keep_color = w.sample_color;
+        w.sample_color = nullptr;
+        free_work(w);
+        w.sample_color = keep_color; w.n0 = keep_n0;
         size_t cap2 = cap, lv = (size_t)levels;
-        HIPCHK(c, hipMalloc((void**)&c->d_rays[0], sizeof(RayRec) * cap2));
-        HIPCHK(c, hipMalloc((void**)&c->d_rays[1], sizeof(RayRec) * cap2));
-        HIPCHK(c, hipMalloc((void**)&c->pool.parent, sizeof(int) * cap2 * lv));
-        HIPCHK(c, hipMalloc((void**)&c->pool.c, sizeof(float4) * cap2 * lv));
-        HIPCHK(c, hipMalloc((void**)&c->pool.d, sizeof(float4) * cap2 * lv));
-        if (dbg) HIPCHK(c, hipMalloc((void**)&c->pool.dbg, sizeof(int) * cap2 * lv));
+        HIPCHK(c, hipMalloc((void**)&w.rays[0], sizeof(RayRec) * cap2));
+        HIPCHK(c, hipMalloc((void**)&w.rays[1], sizeof(RayRec) * cap2));
+        HIPCHK(c, hipMalloc((void**)&w.pool.parent, sizeof(int) * cap2 * lv));
+        HIPCHK(c, hipMalloc((void**)&w.pool.c, sizeof(float4) * cap2 * lv));
+        HIPCHK(c, hipMalloc((void**)&w.pool.d, sizeof(float4) * cap2 * lv));
+        if (dbg) HIPCHK(c, hipMalloc((void**)&w.pool.dbg, sizeof(int) * cap2 * lv));
         if (c->use_bvh) {
-            HIPCHK(c, hipMalloc((void**)&c->d_hits, sizeof(uint2) * cap2));
+            HIPCHK(c, hipMalloc((void**)&w.hits, sizeof(uint2) * cap2));
             for (int k = 0; k < 2; ++k) {
-                HIPCHK(c, hipMalloc((void**)&c->d_src_a[k], sizeof(float4) * cap2));
-                HIPCHK(c, hipMalloc((void**)&c->d_src_b[k], sizeof(float4) * cap2));
+                HIPCHK(c, hipMalloc((void**)&w.src_a[k], sizeof(float4) * cap2));
+                HIPCHK(c, hipMalloc((void**)&w.src_b[k], sizeof(float4) * cap2));
             }
         }
-        HIPCHK(c, hipMalloc((void**)&c->pool.li, sizeof(float) * cap2 * lv * (size_t)(c->sc.n_lights > 0 ? c->sc.n_lights : 1)));
-        c->li_lights = c->sc.n_lights;
-        c->cap_alloc = cap2; c->levels_alloc = levels;
+        HIPCHK(c, hipMalloc((void**)&w.pool.li, sizeof(float) * cap2 * lv * (size_t)(c->sc.n_lights > 0 ? c->sc.n_lights : 1)));
+        w.li_lights = c->sc.n_lights;
+        w.cap = cap2; w.levels = levels;
     }
-    if (n0 > c->n0_alloc) {
-        hipFree(c->d_sample_color); c->d_sample_color = nullptr; c->n0_alloc = 0;
-        c->work_gen++;
-        HIPCHK(c, hipMalloc((void**)&c->d_sample_color, sizeof(float4) * n0));
-        c->n0_alloc = n0;
+    if (n0 > w.n0) {
+        hipFree(w.sample_color); w.sample_color = nullptr; w.n0 = 0;
+        w.gen++;
+        HIPCHK(c, hipMalloc((void**)&w.sample_color, sizeof(float4) * n0));
+        w.n0 = n0;
     }
     return T3D_OK;
 }
@@ -1745,6 +1796,7 @@ static int check_opts(t3d_ctx* c, const t3d_opts* o, int row0, int nrows) {
     if (!o || o->width <= 0 || o->height <= 0 || o->bounces < 0 || o->samples < 1) { c->err = "bad options"; return T3D_E_INVALID; }
     if (o->bounces > T3D_MAX_BOUNCES) { c->err = "bounces above the supported maximum (14)"; return T3D_E_CAPACITY; }
     if (o->samples > 65535) { c->err = "samples above the supported maximum (65535)"; return T3D_E_CAPACITY; }
+    if (!std::isfinite(o->ambient[0]) || !std::isfinite(o->ambient[1]) || !std::isfinite(o->ambient[2])) { c->err = "ambient colour is not finite"; return T3D_E_INVALID; }
     if (o->rng_mode != T3D_RNG_KEYED) { c->err = "the HIP library implements the keyed random mode only"; return T3D_E_INVALID; }
     {
         long stride = o->row_stride > 1 ? o->row_stride : 1;
@@ -1803,36 +1855,48 @@ static void fill_stats(t3d_ctx* c, t3d_stats* stats) {
     stats->n_k_level += (uint64_t)levels;
 }
 
-// Trace one band whose outputs are device pointers.  Returns T3D_E_CAPACITY if a level overflowed
-// its queue (the caller retries with a larger capacity factor or fewer rows).
-static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int cap_factor, uint8_t* d_bgr, float* d_rad,
+// Trace one band whose outputs are device pointers, with the work buffers `w` (grown as needed unless `fixed_work`:
+// then `w` has been laid out by the caller and must already hold `cap_factor` entries per primary sample).  Returns
+// T3D_E_CAPACITY if a level overflowed its queue (the caller retries with a larger capacity factor or fewer rows).
+static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int nrows, int cap_factor, uint8_t* d_bgr, float* d_rad,
                        int32_t* d_prim, float* d_prim_t, hipStream_t st, t3d_stats* stats, const RenderParams* single,
-                       t3d_node* d_dbg, int dbg_cap) {
+                       t3d_node* d_dbg, int dbg_cap, bool fixed_work = false, size_t min_cap = 0) {
     const int S = o->bounces > 1 ? o->samples : 1;  // T3DR.py:1209
     const size_t n0 = single ? 1 : (size_t)nrows * o->width * S;
     const int levels = o->bounces + 1;
+    const int shard_bits = single ? 0 : 6;   // the tree of a single ray lives in one shard, worked on by one workgroup
+    static_assert((1 << 6) == T3D_SHARDS, "shard_bits");
+    const size_t shards = (size_t)1 << shard_bits;
     size_t cap = n0 * (size_t)cap_factor;
-    if (cap < 64 * 1024) cap = 64 * 1024;   // at least 1024 entries per queue shard
-    cap = (cap + (size_t)T3D_SHARDS * 64 - 1) / ((size_t)T3D_SHARDS * 64) * ((size_t)T3D_SHARDS * 64);
+    if (!single && cap < 64 * 1024) cap = 64 * 1024;   // at least 1024 entries per queue shard
+    if (cap < min_cap && min_cap * (size_t)levels <= (size_t)0x7FFFFFF0) cap = min_cap;
+    cap = (cap + shards * 64 - 1) / (shards * 64) * (shards * 64);
     if (cap * (size_t)levels > (size_t)0x7FFFFFF0) { c->err = "band too large for 32-bit node indices"; return T3D_E_CAPACITY; }
-    int rc = ensure_work(c, cap, levels, n0, single != nullptr);
-    if (rc) return rc;
+    if (fixed_work) {
+        if (cap > w.cap || levels > w.levels || n0 > w.n0) { c->err = "render_band: fixed work buffers too small"; return T3D_E_CAPACITY; }
+    } else {
+        int rc = ensure_work(c, w, cap, levels, n0, single != nullptr);
+        if (rc) return rc;
+    }
 
     RenderParams rp{};
     rp.width = o->width; rp.height = o->height; rp.row0 = row0; rp.nrows = single ? 1 : nrows;
     rp.row_stride = o->row_stride > 1 ? o->row_stride : 1;
     rp.bounces = o->bounces; rp.samples = single ? 1 : S; rp.lights = o->lights; rp.seed = o->seed;
     for (int k = 0; k < 3; ++k) rp.ambient[k] = (float)o->ambient[k];
-    rp.cap = (int)c->cap_alloc;
+    rp.cap = (int)(fixed_work ? cap : w.cap);
     rp.n0 = (int)n0;
     rp.resident_waves = c->n_sm * 16;   // 4 waves per SIMD at this kernel's register count
     rp.tiled = !single && o->width % 16 == 0 && nrows % 8 == 0;
     rp.full_rounds = c->full_rounds && !single;
+    rp.shard_bits = shard_bits;
+    rp.sticky = c->h_sticky;
     if (single) {
         rp.single = single->single; rp.px0 = single->px0; rp.py0 = single->py0; rp.sample0 = single->sample0; rp.want_debug = 1;
         for (int k = 0; k < 3; ++k) { rp.ray_o[k] = single->ray_o[k]; rp.ray_d[k] = single->ray_d[k]; }
         rp.ray_ior = single->ray_ior; rp.ray_obj = single->ray_obj;
     }
+    const size_t cap_used = (size_t)rp.cap;
 
     static_assert(sizeof(Counters) % sizeof(uint4) == 0, "k_resolve clears the counters in 16-byte pieces");
     c->d_cnt = c->d_cnt_pair[c->cnt_idx];               // all zero: cleared by the band before (or at creation) ...
@@ -1843,7 +1907,7 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
     if (c->use_bvh) HIPCHK(c, hipMemsetAsync(c->d_fetch, 0, sizeof(PaddedCount) * (size_t)levels * 2 * T3D_SHARDS, st));
     // one sample per pixel: the kernels that finish a sample write the pixel themselves, and k_finish is not launched
     const bool direct = !single && rp.samples == 1;
-    TraceOut out{c->d_sample_color, d_prim, d_prim_t, d_dbg, dbg_cap, direct ? d_bgr : nullptr, direct ? d_rad : nullptr};
+    TraceOut out{w.sample_color, d_prim, d_prim_t, d_dbg, dbg_cap, direct ? d_bgr : nullptr, direct ? d_rad : nullptr};
     const int max_blocks = c->n_sm * 8;
     auto blocks_for = [&](size_t n) { size_t b = (n + T3D_BLOCK - 1) / T3D_BLOCK; return (int)(b < 1 ? 1 : (b > (size_t)max_blocks ? (size_t)max_blocks : b)); };
     // grids of the sharded kernels hold a multiple of T3D_SHARDS waves
@@ -1869,21 +1933,25 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
         b = (b + grid_unit - 1) / grid_unit * grid_unit;
         return (int)b;
     };
+    // A caller that wants to be able to stop a render is asked between the levels: the stream is drained after every
+    // level's launches, which costs the overlap of host and device and is only done while a cancel callback is installed.
+    const bool cancellable = c->cancel_cb != nullptr && !single;
+    bool cancelled = false;
     // per-level timing wants the levels one after the other
-    const bool overlap = c->use_bvh && !c->timing && !single;
+    const bool overlap = c->use_bvh && !c->timing && !single && !cancellable;
     // a call that stays asynchronous and is not being timed gets no events at all: each one is a stop in the stream
     const bool events = c->timing || stats || single;
     // ---- launch graph of a repeated band (brute-force path, nothing but kernels in the stream) ----
     char key[sizeof c->graphs[0].key];
     static_assert(sizeof(RenderParams) + 12 * sizeof(void*) <= sizeof key, "graph key");
-    const bool graphable = c->graphs_enabled && !events && !single && !c->use_bvh;
+    const bool graphable = c->graphs_enabled && !events && !single && !c->use_bvh && !cancellable && !fixed_work;
     bool capturing = false;
     t3d_ctx::FrameGraph* slot = nullptr;
     if (graphable) {
         memset(key, 0, sizeof key);
         memcpy(key, &rp, sizeof rp);
-        const void* ptrs[12] = {d_bgr, d_rad, d_prim, d_prim_t, c->d_cnt, next_cnt, c->d_rays[0], c->d_rays[1], c->pool.c, c->pool.li,
-                                c->d_sample_color, (const void*)(uintptr_t)((c->scene_gen << 32) ^ c->work_gen)};
+        const void* ptrs[12] = {d_bgr, d_rad, d_prim, d_prim_t, c->d_cnt, next_cnt, w.rays[0], w.rays[1], w.pool.c, w.pool.li,
+                                w.sample_color, (const void*)(uintptr_t)((c->scene_gen << 32) ^ w.gen)};
         memcpy(key + sizeof rp, ptrs, sizeof ptrs);
         for (auto& g : c->graphs)
             if (g.valid && memcmp(g.key, key, sizeof key) == 0) {
@@ -1901,23 +1969,23 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
     }
     if (events) HIPCHK(c, tick());  // ev[0]: start of the call
     for (int d = 0; d < levels; ++d) {
-        RayRec* in = c->d_rays[d & 1];
-        RayRec* outq = c->d_rays[(d + 1) & 1];
-        const int grid_n = single ? (int)grid_unit : trace_blocks_for(d == 0 ? n0 : c->cap_alloc);
+        RayRec* in = w.rays[d & 1];
+        RayRec* outq = w.rays[(d + 1) & 1];
+        const int grid_n = single ? 1 : trace_blocks_for(d == 0 ? n0 : cap_used);
         if (c->use_bvh) {
-            const int grid_r = single ? (int)grid_unit : resident_blocks_for(d == 0 ? n0 : c->cap_alloc);
+            const int grid_r = single ? 1 : resident_blocks_for(d == 0 ? n0 : cap_used);
             PaddedCount* fetch_t = c->d_fetch + (size_t)d * 2 * T3D_SHARDS;
-            float4* src_a = c->d_src_a[d & 1];
-            float4* src_b = c->d_src_b[d & 1];
+            float4* src_a = w.src_a[d & 1];
+            float4* src_b = w.src_b[d & 1];
             // the classification of level d overwrites the shading inputs that the shadow rays of level d - 2 read
             if (overlap && d >= 2 && c->sc.n_lights > 0) HIPCHK(c, hipStreamWaitEvent(st, c->ev_shadowed[d - 2], 0));
             if (d == 0) {
-                hipLaunchKernelGGL(k_bvh_trace<true>, dim3(grid_r), dim3(T3D_BLOCK), 0, st, c->sc, sph, rp, d, in, c->d_hits, c->d_cnt, fetch_t);
-                hipLaunchKernelGGL(k_bvh_process<true>, dim3(grid_n), dim3(T3D_BLOCK), 0, st, c->sc, sph, rp, d, in, outq, c->d_hits, c->pool,
+                hipLaunchKernelGGL(k_bvh_trace<true>, dim3(grid_r), dim3(T3D_BLOCK), 0, st, c->sc, sph, rp, d, in, w.hits, c->d_cnt, fetch_t);
+                hipLaunchKernelGGL(k_bvh_process<true>, dim3(grid_n), dim3(T3D_BLOCK), 0, st, c->sc, sph, rp, d, in, outq, w.hits, w.pool,
                                    c->d_cnt, out, src_a, src_b);
             } else {
-                hipLaunchKernelGGL(k_bvh_trace<false>, dim3(grid_r), dim3(T3D_BLOCK), 0, st, c->sc, sph, rp, d, in, c->d_hits, c->d_cnt, fetch_t);
-                hipLaunchKernelGGL(k_bvh_process<false>, dim3(grid_n), dim3(T3D_BLOCK), 0, st, c->sc, sph, rp, d, in, outq, c->d_hits, c->pool,
+                hipLaunchKernelGGL(k_bvh_trace<false>, dim3(grid_r), dim3(T3D_BLOCK), 0, st, c->sc, sph, rp, d, in, w.hits, c->d_cnt, fetch_t);
+                hipLaunchKernelGGL(k_bvh_process<false>, dim3(grid_n), dim3(T3D_BLOCK), 0, st, c->sc, sph, rp, d, in, outq, w.hits, w.pool,
                                    c->d_cnt, out, src_a, src_b);
             }
             launches += 2;
@@ -1929,32 +1997,43 @@ static int render_band(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, int c
                     HIPCHK(c, hipEventRecord(c->ev_traced[d], st));
                     HIPCHK(c, hipStreamWaitEvent(ss, c->ev_traced[d], 0));
                 }
-                const size_t pairs = (d == 0 ? n0 : c->cap_alloc) * (size_t)c->sc.n_lights;
-                hipLaunchKernelGGL(k_bvh_shadow, dim3(single ? (int)grid_unit : resident_blocks_for(pairs)), dim3(T3D_BLOCK), 0, ss, c->sc, sph, rp,
-                                   d, src_a, src_b, c->pool, c->d_cnt, fetch_t + T3D_SHARDS);
+                const size_t pairs = (d == 0 ? n0 : cap_used) * (size_t)c->sc.n_lights;
+                hipLaunchKernelGGL(k_bvh_shadow, dim3(single ? 1 : resident_blocks_for(pairs)), dim3(T3D_BLOCK), 0, ss, c->sc, sph, rp,
+                                   d, src_a, src_b, w.pool, c->d_cnt, fetch_t + T3D_SHARDS);
                 if (overlap) HIPCHK(c, hipEventRecord(c->ev_shadowed[d], ss));
                 launches += 1;
             }
         } else {
             if (d == 0)
                 hipLaunchKernelGGL(k_level<true>, dim3(grid_n), dim3(T3D_BLOCK), 0, st, c->sc, planes, pfirst, uv, sph, rp, d, in, outq,
-                                   c->pool, c->d_cnt, out);
+                                   w.pool, c->d_cnt, out);
             else
                 hipLaunchKernelGGL(k_level<false>, dim3(grid_n), dim3(T3D_BLOCK), 0, st, c->sc, planes, pfirst, uv, sph, rp, d, in, outq,
-                                   c->pool, c->d_cnt, out);
+                                   w.pool, c->d_cnt, out);
             launches += 1;
         }
         if (c->timing) HIPCHK(c, tick());  // ev[1 + d]: level d traced
+        if (cancellable) {
+            HIPCHK(c, hipStreamSynchronize(st));
+            if (c->cancel_cb(c->cancel_user)) { cancelled = true; break; }
+        }
+    }
+    if (cancelled) {
+        // the counters of this band and of the next one are in an unknown state: the next band clears its own at its start
+        // (cnt_clean stays false) and, in its last kernel, the pair's other set
+        c->last_valid = false;
+        c->err = "render cancelled by the caller's cancel callback";
+        return T3D_E_CANCELLED;
     }
     if (overlap && c->sc.n_lights > 0)   // the resolve reads every level's light intensities
         for (int d = levels >= 2 ? levels - 2 : 0; d < levels; ++d) HIPCHK(c, hipStreamWaitEvent(st, c->ev_shadowed[d], 0));
     for (int d = levels - 1; d >= 0; --d) {
-        hipLaunchKernelGGL(k_resolve, dim3(single ? (int)grid_unit : trace_blocks_for(c->cap_alloc)), dim3(T3D_BLOCK), 0, st, c->sc, rp, d, c->pool, c->d_cnt,
-                           c->d_sample_color, d_dbg, dbg_cap, out.bgr, out.radiance, (uint4*)next_cnt, (int)(sizeof(Counters) / sizeof(uint4)));
+        hipLaunchKernelGGL(k_resolve, dim3(single ? 1 : trace_blocks_for(cap_used)), dim3(T3D_BLOCK), 0, st, c->sc, rp, d, w.pool, c->d_cnt,
+                           w.sample_color, d_dbg, dbg_cap, out.bgr, out.radiance, (uint4*)next_cnt, (int)(sizeof(Counters) / sizeof(uint4)));
         launches++;
     }
     if (!single && !direct) {
-        hipLaunchKernelGGL(k_finish, dim3(blocks_for((size_t)nrows * o->width)), dim3(T3D_BLOCK), 0, st, rp, c->d_sample_color, d_bgr, d_rad);
+        hipLaunchKernelGGL(k_finish, dim3(blocks_for((size_t)nrows * o->width)), dim3(T3D_BLOCK), 0, st, rp, w.sample_color, d_bgr, d_rad);
         launches++;
     }
     if (capturing) {
@@ -1988,11 +2067,27 @@ issued:
     c->last_events = events;
     c->last_levels = levels; c->last_n0 = n0; c->last_lights = o->lights; c->last_launches = launches; c->last_stream = st;
     c->last_valid = true;
-    if (!stats && !single) return T3D_OK;  // asynchronous use: overflow is not checked
+    if (!stats && !single) { c->last_async_cap = cap_used; return T3D_OK; }  // asynchronous use: an overflow raises the context's sticky words, see t3d_ctx
     HIPCHK(c, hipStreamSynchronize(st));
-    if (c->h_cnt->overflow) return T3D_E_CAPACITY;
-    if (c->h_cnt->bvh_stack_overflow) { c->err = "LBVH traversal stack overflow"; return T3D_E_DEVICE; }
+    if (c->h_cnt->overflow) { c->h_sticky[0] = 0; return T3D_E_CAPACITY; }   // seen and dealt with by the caller: not left standing
+    if (c->h_cnt->bvh_stack_overflow) { c->h_sticky[1] = 0; c->err = "LBVH traversal stack overflow"; return T3D_E_DEVICE; }
     if (stats) fill_stats(c, stats);
+    return T3D_OK;
+}
+
+// Overflow left behind by an earlier asynchronous call on this context (see t3d_ctx::h_sticky): reported once, then cleared.
+static int take_sticky(t3d_ctx* c) {
+    if (c->h_sticky[1]) {
+        c->h_sticky[0] = c->h_sticky[1] = 0;
+        c->err = "an earlier asynchronous render call overflowed the LBVH traversal stack; its output is invalid";
+        return T3D_E_DEVICE;
+    }
+    if (c->h_sticky[0]) {
+        c->h_sticky[0] = 0;
+        c->async_min_cap = 2 * (c->last_async_cap > c->async_min_cap ? c->last_async_cap : c->async_min_cap);
+        c->err = "an earlier asynchronous render call overflowed its node buffers (its output is invalid); asynchronous calls use larger buffers from now on";
+        return T3D_E_CAPACITY;
+    }
     return T3D_OK;
 }
 
@@ -2003,6 +2098,7 @@ extern "C" int t3d_render_rows_device(t3d_ctx* c, const t3d_opts* o, int row0, i
     if (rc) return rc;
     if (!bgr_device) { c->err = "bgr output is required"; return T3D_E_INVALID; }
     HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = take_sticky(c)) != T3D_OK) return rc;
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     if (stats) memset(stats, 0, sizeof *stats);
     const int S = o->bounces > 1 ? o->samples : 1;
@@ -2016,19 +2112,23 @@ extern "C" int t3d_render_rows_device(t3d_ctx* c, const t3d_opts* o, int row0, i
     int band = (int)(max_samples / ((size_t)o->width * S));
     if (band < 1) band = 1;
     if (band > nrows) band = nrows;
+    // a level holds at most 2^bounces rays per sample; a band of few samples is worked on by few waves, whose
+    // rays all land in those waves' shards, so the bound on the factor counts every shard
+    const int factor_limit = (1 << o->bounces) * T3D_SHARDS;
     for (int r = 0; r < nrows;) {
+        if (c->cancel_cb && c->cancel_cb(c->cancel_user)) { c->last_valid = false; c->err = "render cancelled by the caller's cancel callback"; return T3D_E_CANCELLED; }
         int nb = band < nrows - r ? band : nrows - r;
         size_t off = (size_t)r * o->width;
         int factor = 2;
+        // a call without stats cannot see an overflow and try again: it starts from what earlier overflows have taught
+        const size_t min_cap = stats ? 0 : c->async_min_cap;
         for (;;) {
             t3d_stats band_stats{};
             // capacity overflow can only be seen after a synchronisation; without stats the call stays asynchronous
-            rc = render_band(c, o, row0 + r * (o->row_stride > 1 ? o->row_stride : 1), nb, factor, bgr_device + 3 * off, radiance_device ? radiance_device + 3 * off : nullptr,
+            rc = render_band(c, c->work, o, row0 + r * (o->row_stride > 1 ? o->row_stride : 1), nb, factor, bgr_device + 3 * off, radiance_device ? radiance_device + 3 * off : nullptr,
                              primary_device ? primary_device + 2 * off : nullptr, primary_t_device ? primary_t_device + off : nullptr, st,
-                             stats ? &band_stats : nullptr, nullptr, nullptr, 0);
-            // a level holds at most 2^bounces rays per sample; a band of few samples is worked on by few waves, whose
-            // rays all land in those waves' shards, so the bound on the factor counts every shard
-            if (rc == T3D_E_CAPACITY && factor < (1 << o->bounces) * T3D_SHARDS) {
+                             stats ? &band_stats : nullptr, nullptr, nullptr, 0, false, min_cap);
+            if (rc == T3D_E_CAPACITY && factor < factor_limit) {
                 const size_t next_cap = (size_t)nb * o->width * S * (size_t)factor * 2;   // entries per level after doubling
                 size_t need = next_cap * per_sample / 2;
                 // fewer rows instead, where doubling would leave the budget or the 32-bit node indices
@@ -2085,8 +2185,32 @@ extern "C" int t3d_last_call_stats(t3d_ctx* c, t3d_stats* stats) {
     }
     HIPCHK(c, hipStreamSynchronize(c->last_stream));
     memset(stats, 0, sizeof *stats);
+    // the sticky words cover every band of the call (and any earlier asynchronous call nobody has asked about), the
+    // counters only its last band
+    int rc = take_sticky(c);
+    if (rc != T3D_OK) return rc;
     if (c->h_cnt->overflow) { c->err = "trace tree did not fit the node buffers"; return T3D_E_CAPACITY; }
     fill_stats(c, stats);
+    return T3D_OK;
+}
+
+extern "C" int t3d_set_cancel(t3d_ctx* c, int (*poll)(void*), void* user) {
+    if (!c) return T3D_E_INVALID;
+    c->cancel_cb = poll; c->cancel_user = user;
+    return T3D_OK;
+}
+
+// device-side outputs of the entry points that hand back host memory
+static int ensure_outputs(t3d_ctx* c, size_t npix) {
+    if (npix > c->out_alloc) {
+        hipFree(c->d_bgr); hipFree(c->d_rad); hipFree(c->d_prim); hipFree(c->d_prim_t);
+        c->d_bgr = nullptr; c->d_rad = nullptr; c->d_prim = nullptr; c->d_prim_t = nullptr; c->out_alloc = 0;
+        HIPCHK(c, hipMalloc((void**)&c->d_bgr, npix * 3));
+        HIPCHK(c, hipMalloc((void**)&c->d_rad, npix * 3 * sizeof(float)));
+        HIPCHK(c, hipMalloc((void**)&c->d_prim, npix * 2 * sizeof(int32_t)));
+        HIPCHK(c, hipMalloc((void**)&c->d_prim_t, npix * sizeof(float)));
+        c->out_alloc = npix;
+    }
     return T3D_OK;
 }
 
@@ -2097,15 +2221,7 @@ extern "C" int t3d_render_rows(t3d_ctx* c, const t3d_opts* o, int row0, int nrow
     if (!bgr_out) { c->err = "bgr output is required"; return T3D_E_INVALID; }
     HIPCHK(c, hipSetDevice(c->device));
     size_t npix = (size_t)nrows * o->width;
-    if (npix > c->out_alloc) {
-        hipFree(c->d_bgr); hipFree(c->d_rad); hipFree(c->d_prim); hipFree(c->d_prim_t);
-        c->d_bgr = nullptr; c->d_rad = nullptr; c->d_prim = nullptr; c->d_prim_t = nullptr; c->out_alloc = 0;
-        HIPCHK(c, hipMalloc((void**)&c->d_bgr, npix * 3));
-        HIPCHK(c, hipMalloc((void**)&c->d_rad, npix * 3 * sizeof(float)));
-        HIPCHK(c, hipMalloc((void**)&c->d_prim, npix * 2 * sizeof(int32_t)));
-        HIPCHK(c, hipMalloc((void**)&c->d_prim_t, npix * sizeof(float)));
-        c->out_alloc = npix;
-    }
+    if ((rc = ensure_outputs(c, npix)) != T3D_OK) return rc;
     t3d_stats local{};
     rc = t3d_render_rows_device(c, o, row0, nrows, c->d_bgr, radiance_out ? c->d_rad : nullptr, primary_out ? c->d_prim : nullptr,
                                 primary_t_out ? c->d_prim_t : nullptr, nullptr, &local);
@@ -2136,42 +2252,138 @@ extern "C" int t3d_render_rows(t3d_ctx* c, const t3d_opts* o, int row0, int nrow
     return T3D_OK;
 }
 
+extern "C" int t3d_host_alloc(size_t bytes, void** out) {
+    if (!out || bytes == 0) return T3D_E_INVALID;
+    *out = nullptr;
+    return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? T3D_OK : T3D_E_NOMEM;
+}
+
+extern "C" int t3d_host_free(void* p) {
+    if (!p) return T3D_OK;
+    return hipHostFree(p) == hipSuccess ? T3D_OK : T3D_E_INVALID;
+}
+
+extern "C" int t3d_render_rows_async(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, uint8_t* bgr_pinned) {
+    int rc = check_opts(c, o, row0, nrows);
+    if (rc) return rc;
+    if (!bgr_pinned) { c->err = "bgr output is required"; return T3D_E_INVALID; }
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t npix = (size_t)nrows * o->width;
+    if ((rc = ensure_outputs(c, npix)) != T3D_OK) return rc;
+    rc = t3d_render_rows_device(c, o, row0, nrows, c->d_bgr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(bgr_pinned, c->d_bgr, npix * 3, hipMemcpyDeviceToHost, c->stream));
+    return T3D_OK;
+}
+
+// One frame on several devices (or several contexts of one device): context k renders image rows k, k + n, k + 2n, ...
+// (pixels are independent and the random numbers are keyed by absolute pixel coordinates, so the picture does not depend
+// on the partition) and copies them, with one strided copy on its own stream, straight to their places in the frame:
+// the reference's stripes per thread and the np.vstack that joins them (T3DR.py:1111-1165).  One host thread per
+// context, so the launches of the devices do not queue up behind each other on the host.
+extern "C" int t3d_render_frame_multi(t3d_ctx* const* ctxs, int n, const t3d_opts* o, uint8_t* bgr_frame, int frame_on_device,
+                                      t3d_stats* stats) {
+    if (!ctxs || n < 1 || !ctxs[0]) return T3D_E_INVALID;
+    t3d_ctx* c0 = ctxs[0];
+    for (int k = 0; k < n; ++k) if (!ctxs[k]) { c0->err = "t3d_render_frame_multi: null context"; return T3D_E_INVALID; }
+    for (int k = 0; k < n; ++k) for (int j = 0; j < k; ++j) if (ctxs[j] == ctxs[k]) { c0->err = "t3d_render_frame_multi: the same context twice"; return T3D_E_INVALID; }
+    if (!o || !bgr_frame) { c0->err = "t3d_render_frame_multi: bad argument"; return T3D_E_INVALID; }
+    if (o->height <= 0 || o->height % n != 0) { c0->err = "Number of GPUs must be a factor of image height"; return T3D_E_INVALID; }
+    const int rows = o->height / n;
+    std::vector<int> rcs((size_t)n, T3D_OK);
+    std::vector<t3d_stats> sts((size_t)n);
+    auto work = [&](int k) {
+        t3d_ctx* c = ctxs[k];
+        t3d_opts ok = *o;
+        ok.row_stride = n;
+        int rc = check_opts(c, &ok, k, rows);
+        if (rc == T3D_OK && hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; rc = T3D_E_DEVICE; }
+        if (rc == T3D_OK) rc = ensure_outputs(c, (size_t)rows * o->width);
+        const size_t line = (size_t)o->width * 3;
+        auto place = [&]() -> int {   // the gather: tile rows to frame rows k, k + n, ...
+            hipError_t e = hipMemcpy2DAsync(bgr_frame + (size_t)k * line, line * n, c->d_bgr, line, line, rows,
+                                            frame_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream);
+            if (e != hipSuccess) { c->err = std::string("t3d_render_frame_multi: tile copy: ") + hipGetErrorString(e); return T3D_E_DEVICE; }
+            return T3D_OK;
+        };
+        if (rc == T3D_OK) rc = t3d_render_rows_device(c, &ok, k, rows, c->d_bgr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        if (rc == T3D_OK) rc = place();
+        if (rc == T3D_OK) rc = t3d_last_call_stats(c, &sts[k]);
+        if (rc == T3D_E_CAPACITY) {
+            // the trees outgrew the buffers of the unchecked call: once more, checked, which grows them
+            rc = t3d_render_rows_device(c, &ok, k, rows, c->d_bgr, nullptr, nullptr, nullptr, nullptr, &sts[k]);
+            if (rc == T3D_OK) rc = place();
+            if (rc == T3D_OK && hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "t3d_render_frame_multi: synchronise failed"; rc = T3D_E_DEVICE; }
+        }
+        rcs[k] = rc;
+    };
+    if (n == 1) work(0);
+    else {
+        std::vector<std::thread> threads;
+        for (int k = 0; k < n; ++k) threads.emplace_back(work, k);
+        for (auto& t : threads) t.join();
+    }
+    for (int k = 0; k < n; ++k)
+        if (rcs[k] != T3D_OK) { if (k) c0->err = "context " + std::to_string(k) + ": " + ctxs[k]->err; return rcs[k]; }
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        for (int k = 0; k < n; ++k) {
+            uint64_t* dst = &stats->rays_api; const uint64_t* src = &sts[k].rays_api;
+            for (int q = 0; q < T3D_STATS_N_COUNTERS; ++q) dst[q] += src[q];
+            // the devices work side by side: the frame's device time is the slowest tile's
+            stats->ms_device = fmax(stats->ms_device, sts[k].ms_device); stats->ms_k_level = fmax(stats->ms_k_level, sts[k].ms_k_level);
+            stats->ms_resolve = fmax(stats->ms_resolve, sts[k].ms_resolve);
+            for (int q = 0; q < T3D_STATS_MAX_LEVELS; ++q) {
+                stats->level_rays[q] += sts[k].level_rays[q]; stats->level_nodes[q] += sts[k].level_nodes[q];
+                stats->level_ms[q] = fmax(stats->level_ms[q], sts[k].level_ms[q]);
+            }
+            stats->bvh_deep_pushes += sts[k].bvh_deep_pushes;
+        }
+    }
+    return T3D_OK;
+}
+
 // One initial ray through every level; its tree in depth-first order (bounce child before transmit child).
 static int trace_single(t3d_ctx* c, const t3d_opts* o, const RenderParams& single, int row, t3d_node* nodes, int capacity) {
     HIPCHK(c, hipSetDevice(c->device));
-    const int worst = (1 << (o->bounces + 1)) - 1;
-    const int dbg_cap = worst < 65536 ? worst : 65536;
-    t3d_node* d_dbg = nullptr;
-    HIPCHK(c, hipMalloc((void**)&d_dbg, sizeof(t3d_node) * dbg_cap));
+    int rc = take_sticky(c);
+    if (rc != T3D_OK) return rc;
+    const int worst = (1 << (o->bounces + 1)) - 1;   // a full binary tree: T3D_MAX_BOUNCES keeps this below 2^15
+    const int dbg_cap = worst;
+    if (dbg_cap > c->dbg_alloc) {
+        hipFree(c->d_dbg); c->d_dbg = nullptr; c->dbg_alloc = 0;
+        HIPCHK(c, hipMalloc((void**)&c->d_dbg, sizeof(t3d_node) * dbg_cap));
+        c->dbg_alloc = dbg_cap;
+    }
+    t3d_node* d_dbg = c->d_dbg;
     t3d_stats st{};
-    // capacity factor: a single sample can branch at every level
-    // all nodes of a single-pixel tree land in one queue shard: a shard must hold a full level (2^bounces rays)
-    int factor = T3D_SHARDS * (1 << o->bounces);
-    int rc = render_band(c, o, row, 1, factor, nullptr, nullptr, nullptr, nullptr, c->stream, &st, &single, d_dbg, dbg_cap);
+    // The whole tree lives in one queue shard (render_band uses a single shard and a single workgroup for it), and a
+    // level of it holds at most 2^bounces rays: that is all the capacity a level needs.
+    const int factor = 1 << o->bounces;
+    rc = render_band(c, c->single_work, o, row, 1, factor, nullptr, nullptr, nullptr, nullptr, c->stream, &st, &single, d_dbg, dbg_cap);
     int n = 0;
     if (!rc) {
         n = c->h_cnt->n_dbg < dbg_cap ? c->h_cnt->n_dbg : dbg_cap;
         std::vector<t3d_node> tmp((size_t)(n > 0 ? n : 1));
         if (n > 0 && hipMemcpy(tmp.data(), d_dbg, sizeof(t3d_node) * n, hipMemcpyDeviceToHost) != hipSuccess) { rc = T3D_E_DEVICE; c->err = "trace: copy of the node records failed"; }
         if (!rc) {
-            // depth-first order, bounce child (2n) before transmit child (2n+1)
+            // depth-first order, bounce child (2n) before transmit child (2n+1); heap index -> record
+            std::vector<int> where((size_t)worst + 1, -1);
+            for (int i = 0; i < n; ++i) if (tmp[i].heap >= 1 && tmp[i].heap <= worst) where[tmp[i].heap] = i;
             std::vector<int> order;
             std::vector<int> stack;
-            auto find = [&](int heap) { for (int i = 0; i < n; ++i) if (tmp[i].heap == heap) return i; return -1; };
             stack.push_back(1);
             while (!stack.empty()) {
                 int hidx = stack.back(); stack.pop_back();
-                int i = find(hidx);
-                if (i < 0) continue;
-                order.push_back(i);
-                if (2 * hidx + 1 < 65536) { stack.push_back(2 * hidx + 1); stack.push_back(2 * hidx); }
+                if (hidx > worst || where[hidx] < 0) continue;
+                order.push_back(where[hidx]);
+                stack.push_back(2 * hidx + 1); stack.push_back(2 * hidx);
             }
             int m = (int)order.size();
             if (m > capacity) { rc = T3D_E_CAPACITY; c->err = "trace: node buffer too small"; }
             else { for (int i = 0; i < m; ++i) nodes[i] = tmp[order[i]]; n = m; }
         }
     }
-    hipFree(d_dbg);
     return rc ? rc : n;
 }
 
@@ -2206,26 +2418,29 @@ extern "C" int t3d_closest_hits(t3d_ctx* c, int n, const float* origins, const f
     if (n < 0 || !origins || !dirs || !out_obj || !out_face || !out_t || !out_dirflag) { c->err = "t3d_closest_hits: bad argument"; return T3D_E_INVALID; }
     if (n == 0) return T3D_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr, *d_n = nullptr;
-    int32_t *d_obj = nullptr, *d_face = nullptr, *d_dir = nullptr;
-    size_t n3 = (size_t)n * 3 * sizeof(float);
-    int rc = T3D_OK;
-    auto cleanup = [&]() { hipFree(d_o); hipFree(d_d); hipFree(d_t); hipFree(d_n); hipFree(d_obj); hipFree(d_face); hipFree(d_dir); };
-#define CH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { c->err = std::string(#call) + ": " + hipGetErrorString(e_); cleanup(); return T3D_E_DEVICE; } } while (0)
-    CH(hipMalloc((void**)&d_o, n3)); CH(hipMalloc((void**)&d_d, n3)); CH(hipMalloc((void**)&d_t, n * sizeof(float))); CH(hipMalloc((void**)&d_n, n3));
-    CH(hipMalloc((void**)&d_obj, n * sizeof(int32_t))); CH(hipMalloc((void**)&d_face, n * sizeof(int32_t))); CH(hipMalloc((void**)&d_dir, n * sizeof(int32_t)));
-    CH(hipMemcpyAsync(d_o, origins, n3, hipMemcpyHostToDevice, c->stream));
-    CH(hipMemcpyAsync(d_d, dirs, n3, hipMemcpyHostToDevice, c->stream));
+    // The rays and the answers live in one pinned host buffer of the context that the kernel reads and writes in place
+    // (44 bytes in, 32 bytes out per ray over the host link): a picked pixel is a launch and a wait, with no device
+    // allocation and no staged copies.
+    const size_t n3 = (size_t)n * 3 * sizeof(float), n1 = (size_t)n * sizeof(float);
+    const size_t need = 3 * n3 + 4 * n1;
+    if (need > c->pick_alloc) {
+        if (c->h_pick) hipHostFree(c->h_pick);
+        c->h_pick = nullptr; c->pick_alloc = 0;
+        const size_t want = need < 4096 ? 4096 : need + need / 2;
+        HIPCHK(c, hipHostMalloc(&c->h_pick, want, hipHostMallocDefault));
+        c->pick_alloc = want;
+    }
+    char* base = (char*)c->h_pick;
+    float* h_o = (float*)base; float* h_d = (float*)(base + n3); float* h_n = (float*)(base + 2 * n3);
+    float* h_t = (float*)(base + 3 * n3);
+    int32_t* h_obj = (int32_t*)(base + 3 * n3 + n1); int32_t* h_face = (int32_t*)(base + 3 * n3 + 2 * n1); int32_t* h_dir = (int32_t*)(base + 3 * n3 + 3 * n1);
+    memcpy(h_o, origins, n3);
+    memcpy(h_d, dirs, n3);
     hipLaunchKernelGGL(k_closest, dim3((n + T3D_BLOCK - 1) / T3D_BLOCK), dim3(T3D_BLOCK), 0, c->stream, c->sc, (const float4*)c->d_planes,
-                       (const int*)c->d_plane_first, (const float4*)c->d_tri_uv, (const DevSphere*)c->d_spheres, n, d_o, d_d, lights, back_cull, d_obj, d_face, d_t, d_dir, d_n);
-    CH(hipGetLastError());
-    CH(hipMemcpyAsync(out_obj, d_obj, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    CH(hipMemcpyAsync(out_face, d_face, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    CH(hipMemcpyAsync(out_t, d_t, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    CH(hipMemcpyAsync(out_dirflag, d_dir, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    if (out_normal) CH(hipMemcpyAsync(out_normal, d_n, n3, hipMemcpyDeviceToHost, c->stream));
-    CH(hipStreamSynchronize(c->stream));
-#undef CH
-    cleanup();
-    return rc;
+                       (const int*)c->d_plane_first, (const float4*)c->d_tri_uv, (const DevSphere*)c->d_spheres, n, h_o, h_d, lights, back_cull, h_obj, h_face, h_t, h_dir, h_n);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(out_obj, h_obj, n1); memcpy(out_face, h_face, n1); memcpy(out_t, h_t, n1); memcpy(out_dirflag, h_dir, n1);
+    if (out_normal) memcpy(out_normal, h_n, n3);
+    return T3D_OK;
 }

@@ -12,7 +12,8 @@ Differences a caller can observe, all deliberate:
 * random directions for bounce()/transmit() come from the keyed generator in ``keyed_rng`` (option
   ``seed``, default 0), so an image is reproducible and independent of how rows are split.
 * ``Rendered.traces`` is a lazy mapping: ``traces[(x, y)]`` re-traces that pixel on the GPU.
-* extra option keys: ``device`` (HIP device index, default 0), ``seed``.
+* extra option keys: ``device`` (HIP device index, default 0), ``seed``, ``gpus`` (render the frame on that many
+  devices at once, rows interleaved; must divide ``height``) and ``devices`` (which ones).
 """
 from __future__ import annotations
 
@@ -153,6 +154,8 @@ class Photon:
         self._baked = None
         self._uploaded_digest = None
         self.uploads = 0           # scene uploads so far (a re-flattening with an unchanged digest is not one)
+        self._multi = []           # [context, digest of its scene] per GPU when options['gpus'] > 1
+        self._multi_devices = None
         self.scene = scene
         self.options = self.mergeDefaultOptions({} if options is None else options)
         self.rays = 0
@@ -203,21 +206,27 @@ class Photon:
             self._ctx = _native.Context(int(self.options.get("device", 0)))
         return self._ctx
 
-    def _prepare(self, force=False):
-        """Flatten the scene and upload it.  Live-edited scenes (``transformBefore`` False, the
-        picking path of explorer.py:324-355) are re-flattened on every call."""
+    def _prepare(self, force_flatten=False):
+        """Flatten the scene and upload it if it changed.  Live-edited scenes (``transformBefore`` False, the
+        picking path of explorer.py:324-355) are re-flattened on every call, and so is the scene of every
+        ``render()`` (which may have been edited since the last one)."""
         if self._scene.camera is None:
             raise NoBoundCameraError()
-        if force or self._flat is None or not self.options["transformBefore"]:
+        if force_flatten or self._flat is None or not self.options["transformBefore"]:
             flat = flatten_scene(self._scene)
             digest = flat.digest()
-            # an unchanged scene keeps its device copy (plane groups, hierarchy): a picking loop over a scene
-            # that is not being edited pays for the flattening only
-            if force or digest != self._uploaded_digest:
+            # an unchanged scene keeps its device copy (plane groups, hierarchy): a render or a picking loop over a
+            # scene that is not being edited pays for the flattening only
+            if digest != self._uploaded_digest:
                 self._context().upload(flat)
                 self._uploaded_digest = digest
                 self.uploads += 1
             self._flat = flat
+        elif self._uploaded_digest is None:
+            # flattened by the several-GPU path, whose contexts are its own: this one has seen no scene yet
+            self._context().upload(self._flat)
+            self._uploaded_digest = self._flat.digest()
+            self.uploads += 1
         return self._context()
 
     def _native_options(self):
@@ -388,45 +397,132 @@ class Photon:
             node.right = by_heap.get(2 * heap + 1)
         return by_heap.get(1)
 
+    # -- several GPUs -------------------------------------------------------------------------------------
+    def _render_multi(self, gpus, progressCallback, cancelCallback, returnType):
+        """``options['gpus'] = N``: the frame's rows are dealt to N device contexts (rows k, k + N, ... to context k),
+        which render side by side and copy their rows into the frame (``t3d_render_frame_multi``).  Stands where the
+        reference starts ``threads`` stripe threads and stacks their stripes (T3DR.py:1111-1165); like there, N must
+        divide the image height.  ``options['devices']`` may list the HIP device of every context (default 0..N-1).
+        Callbacks fire once, around the whole frame."""
+        opts = self.options
+        width, height = int(opts["width"]), int(opts["height"])
+        if height % gpus != 0:
+            raise ValueError("Number of GPUs must be a factor of image height")
+        devices = [int(d) for d in (opts.get("devices") or range(gpus))]
+        if len(devices) != gpus:
+            raise ValueError("options['devices'] must list one device per GPU")
+        if self._multi_devices != devices:
+            for c, _ in self._multi:
+                c.close()
+            self._multi = [[_native.Context(d), None] for d in devices]
+            self._multi_devices = devices
+        flat = flatten_scene(self._scene)
+        digest = flat.digest()
+        for slot in self._multi:
+            if slot[1] != digest:
+                slot[0].upload(flat)
+                slot[1] = digest
+                self.uploads += 1
+        self._flat, self._baked = flat, True
+        native_opts = self._native_options()
+        seed = int(opts.get("seed", 0))
+        progress = ThreadsProgress(callback=progressCallback or (lambda table, key, total: None), total=height * width)
+        self.threadsProgress = progress
+        progress[0] = 0
+        image = _native.pinned_image((height, width, 3))
+        start = _time.time()
+        failed = bool(cancelCallback and cancelCallback())
+        totals = {}
+        if not failed:
+            totals = _native.render_frame_multi([c for c, _ in self._multi], native_opts, seed, out=image)
+            progress[0] = height * width - 1
+            failed = bool(cancelCallback and cancelCallback())
+        elapsed = _time.time() - start
+        if returnType == "np":
+            return image
+        samples = int(opts["samples"]) if int(opts["bounces"]) > 1 else 1
+        rendered = Rendered(image, LazyTraces(self, width, height, samples, native_opts, seed), width, height, elapsed,
+                            int(totals.get("rays_api", 0)), opts, failed=failed, engine="photon")
+        rendered.stats = totals
+        return rendered
+
     # -- render (T3DR.py:1086-1242) ------------------------------------------------------------------
     def render(self, progressCallback=None, cancelCallback=None, returnType="rendered"):
+        """Render the frame.  The reference deep-copies the scene on every call, so a scene edited between two
+        calls must show; here the scene is flattened again on every call and uploaded only when its fingerprint
+        changed.  When a device copy exists and nobody asked for callbacks, the device starts on the frame at once
+        with that copy while the host does the flattening; the frame is kept if the fingerprint turns out
+        unchanged and rendered again otherwise."""
         if self._scene.camera is None:
             raise NoBoundCameraError()
         opts = self.options
         width, height, stripes = int(opts["width"]), int(opts["height"]), int(opts["threads"])
+        gpus = int(opts.get("gpus", 1) or 1)
         if height % stripes != 0:
             raise ValueError("Number of threads must be a factor of image height")
-        ctx = self._prepare(force=True)
-        self._baked = True  # transformedScene is rebuilt lazily from the current scene
+        if gpus > 1:
+            return self._render_multi(gpus, progressCallback, cancelCallback, returnType)
         native_opts = self._native_options()
         seed = int(opts.get("seed", 0))
-        if progressCallback is None and cancelCallback is None:
+        plain = progressCallback is None and cancelCallback is None
+        if plain:
             stripes = 1
         progressCallback = progressCallback or (lambda table, key, total: None)
         cancelCallback = cancelCallback or (lambda: False)
         stripe_rows = height // stripes
         progress = ThreadsProgress(callback=progressCallback, total=stripe_rows * width)
         self.threadsProgress = progress
-        image = np.zeros((height, width, 3), np.uint8)
+        image = _native.pinned_image((height, width, 3))
         totals = {}
         failed = False
         self.rays = 0
         start = _time.time()
-        for sid in range(stripes):
-            progress[sid] = 0
-            if failed:
-                continue
-            # a stripe is a block of whole rows of the image: the library writes it in place
-            out = ctx.render_rows(native_opts, seed=seed, row0=sid * stripe_rows, nrows=stripe_rows,
-                                  out=image[sid * stripe_rows:(sid + 1) * stripe_rows])
-            for k, v in out["stats"].items():
-                if isinstance(v, list):      # per-level arrays
-                    totals[k] = [a + b for a, b in zip(totals.get(k, [0] * len(v)), v)]
-                else:
-                    totals[k] = totals.get(k, 0) + v
-            progress[sid] = stripe_rows * width - 1
-            if cancelCallback():
-                failed = True
+        early = None
+        if plain and self._ctx is not None and self._uploaded_digest is not None:
+            try:
+                self._ctx.render_rows_async(native_opts, seed, 0, height, image)
+                early = True
+            except _native.NativeError:
+                early = None     # e.g. an overflow left by an earlier call: the checked path below deals with it
+        uploads_before = self.uploads
+        ctx = self._prepare(force_flatten=True)
+        self._baked = True  # transformedScene is rebuilt lazily from the current scene
+        if early and self.uploads == uploads_before:      # the scene the device started on is still the scene
+            try:
+                totals = ctx.last_call_stats()        # waits for the frame started above
+            except _native.NativeError as e:
+                if e.code != _native.E_CAPACITY:
+                    raise
+                early = None                          # the trees outgrew the buffers: render again, checked
+        else:
+            early = None
+        if not early:
+            if not plain:
+                image[:] = 0                          # a cancelled render leaves the rest of the (recycled) buffer black
+                ctx.set_cancel(cancelCallback)
+            try:
+                for sid in range(stripes):
+                    progress[sid] = 0
+                    if failed:
+                        continue
+                    # a stripe is a block of whole rows of the image: the library writes it in place
+                    try:
+                        out = ctx.render_rows(native_opts, seed=seed, row0=sid * stripe_rows, nrows=stripe_rows,
+                                              out=image[sid * stripe_rows:(sid + 1) * stripe_rows])
+                    except _native.Cancelled:
+                        failed = True
+                        continue
+                    for k, v in out["stats"].items():
+                        if isinstance(v, list):      # per-level arrays
+                            totals[k] = [a + b for a, b in zip(totals.get(k, [0] * len(v)), v)]
+                        else:
+                            totals[k] = totals.get(k, 0) + v
+                    progress[sid] = stripe_rows * width - 1
+                    if cancelCallback():
+                        failed = True
+            finally:
+                if not plain:
+                    ctx.set_cancel(None)
         elapsed = _time.time() - start
         rays = int(totals.get("rays_api", 0))
         self.rays = 0

@@ -2,7 +2,7 @@
 
 The Cornell scene follows the reference's demo script (cornellTest.py:7-94): box mesh from
 ``cornellbox.stl`` rotated 90 degrees about y and baked, glass cube, mirror sphere, camera of
-length 20 at (0, 0, -11).  The data files sit in ``tests/golden/scenes``.
+length 20 at (0, 0, -11).  The data files sit in ``raytracing_amd/data``.
 """
 from __future__ import annotations
 
@@ -13,7 +13,7 @@ import numpy as np
 
 from .scene import RGB, Camera, Cube, Light, Material, Mesh, Object, Scale, Scene, Shader, Sphere, Vec3
 
-DATA_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "scenes")
+DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 
 
 def _cornell_box(scene):

@@ -6,7 +6,7 @@ from raytracing_amd.scene import Scene
 from raytracing_amd.flatten import flatten_scene
 from raytracing_amd import _native
 from oracle import oracle
-flat = flatten_scene(Scene.fromJSON(os.path.join(ROOT, "tests/golden/scenes/cornellScene.json")))
+flat = flatten_scene(Scene.fromJSON(os.path.join(ROOT, "raytracing_amd/data/cornellScene.json")))
 ctx = _native.Context(0); ctx.upload(flat)
 rng = np.random.default_rng(0)
 n = 3000

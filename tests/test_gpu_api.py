@@ -1,0 +1,236 @@
+"""Behaviour of the C ABI around the tracing itself: asynchronous calls that overflow, cancellation, the frame on
+several contexts at once, the asynchronous host render, and what ``Photon.render`` builds from them."""
+import numpy as np
+import pytest
+
+from conftest import flat_for, scene_path
+from test_gpu_parity import nested_glass_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def test_async_overflow_is_reported_once_and_buffers_grow(monkeypatch):
+    """An asynchronous call (no stats) whose trace trees outgrow the work buffers cannot say so itself.  The overflow
+    stays on record -- also when the frame was cut into several bands, whose counters replace each other -- until the
+    next look: t3d_last_call_stats, or the next render call, returns T3D_E_CAPACITY once, and asynchronous calls start
+    with larger buffers from then on."""
+    from raytracing_amd import _native
+    flat = nested_glass_scene()
+    opt = dict(width=24, height=16, bounces=9, samples=2)
+    monkeypatch.setenv("T3D_MEM_BUDGET_MB", "1")       # several bands per frame
+    ctx = _native.Context(0)
+    try:
+        ctx.upload(flat)
+        want = ctx.render_rows(opt, seed=5)                      # checked call: grows per band as needed
+        assert want["stats"]["launches"] > 30
+        fresh = _native.Context(0)                               # a context whose buffers have not grown yet
+        try:
+            fresh.upload(flat)
+            img = _native.pinned_image((16, 24, 3))
+            seen = 0
+            for attempt in range(12):
+                fresh.render_rows_async(opt, 5, 0, 16, img)
+                try:
+                    fresh.last_call_stats()
+                    break
+                except _native.NativeError as e:
+                    assert e.code == _native.E_CAPACITY
+                    seen += 1
+            assert seen >= 1, "the first asynchronous frame cannot have fitted buffers sized for two rays per sample"
+            assert attempt < 11 and np.array_equal(img, want["bgr"])
+            # the overflow of a call nobody asked about is reported by the next call instead
+            small = _native.Context(0)
+            try:
+                small.upload(flat)
+                small.render_rows_async(opt, 5, 0, 16, img)
+                import time
+                deadline = time.time() + 5.0
+                with pytest.raises(_native.NativeError) as info:
+                    while time.time() < deadline:                # the flag appears when the kernels have run
+                        small.render_rows_async(opt, 5, 0, 16, img)
+                assert info.value.code == _native.E_CAPACITY
+            finally:
+                small.close()
+        finally:
+            fresh.close()
+    finally:
+        ctx.close()
+
+
+def test_cancel_stops_between_levels_and_the_context_recovers(gpu_ctx):
+    from raytracing_amd import _native
+    flat = flat_for("config2_cornell_light.json")
+    gpu_ctx.upload(flat)
+    opt = dict(width=160, height=96, bounces=4, samples=2)
+    want = gpu_ctx.render_rows(opt, seed=1)
+    polls = []
+
+    def stop_at(k):
+        def poll():
+            polls.append(1)
+            return len(polls) > k
+        return poll
+
+    for k in (0, 1, 3):          # before the band, after its first level, after its third
+        polls.clear()
+        gpu_ctx.set_cancel(stop_at(k))
+        with pytest.raises(_native.Cancelled):
+            gpu_ctx.render_rows(opt, seed=1)
+        assert len(polls) == k + 1
+        with pytest.raises(_native.NativeError):                 # a cancelled call has no statistics
+            gpu_ctx.last_call_stats()
+    polls.clear()
+    gpu_ctx.set_cancel(lambda: polls.append(1) and False)        # asked, never stops: 1 band + 5 levels
+    got = gpu_ctx.render_rows(opt, seed=1)
+    assert len(polls) == 6 and np.array_equal(got["bgr"], want["bgr"]) and got["stats"]["queries"] == want["stats"]["queries"]
+    gpu_ctx.set_cancel(None)
+    polls.clear()
+    again = gpu_ctx.render_rows(opt, seed=1)
+    assert not polls and np.array_equal(again["bgr"], want["bgr"]) and again["stats"]["queries"] == want["stats"]["queries"]
+
+
+@pytest.mark.parametrize("accel", ["brute", "lbvh"])
+def test_frame_on_several_contexts(accel):
+    """t3d_render_frame_multi with three contexts (of the one device a test box has): same frame and counters as one
+    context alone; a height the context count does not divide is refused."""
+    from raytracing_amd import _native
+    flat = flat_for("config2_cornell_light.json")
+    opt = dict(width=96, height=54, bounces=3, samples=2)
+    ctxs = [_native.Context(0) for _ in range(3)]
+    try:
+        for c in ctxs:
+            c.set_accel(accel)
+            c.upload(flat)
+        alone = ctxs[0].render_rows(opt, seed=2)
+        frame = _native.pinned_image((54, 96, 3))
+        frame[:] = 7
+        st = _native.render_frame_multi(ctxs, opt, 2, out=frame)
+        assert np.array_equal(frame, alone["bgr"])
+        for k in ("queries", "rays_api", "nodes", "shadow_queries", "trace_queries"):
+            assert st[k] == alone["stats"][k], k
+        pageable = np.zeros((54, 96, 3), np.uint8)               # any host memory will do, pinned is only faster
+        _native.render_frame_multi(ctxs[:2], opt, 2, out=pageable)
+        assert np.array_equal(pageable, alone["bgr"])
+        with pytest.raises(_native.NativeError, match="factor of image height"):
+            _native.render_frame_multi(ctxs, dict(opt, height=55), 2, out=np.zeros((55, 96, 3), np.uint8))
+        # trees that outgrow the unchecked call's buffers: the tile is rendered again, checked
+        glass = nested_glass_scene()
+        for c in ctxs:
+            c.upload(glass)
+        gopt = dict(width=24, height=18, bounces=9, samples=2)
+        galone = ctxs[0].render_rows(gopt, seed=5)
+        fresh = [_native.Context(0) for _ in range(3)]
+        try:
+            for c in fresh:
+                c.set_accel(accel)
+                c.upload(glass)
+            gframe = _native.pinned_image((18, 24, 3))
+            gst = _native.render_frame_multi(fresh, gopt, 5, out=gframe)
+            assert np.array_equal(gframe, galone["bgr"]) and gst["queries"] == galone["stats"]["queries"]
+        finally:
+            for c in fresh:
+                c.close()
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_frame_on_several_contexts_into_device_memory():
+    import torch
+    from raytracing_amd import _native
+    flat = flat_for("cornellScene.json")
+    opt = dict(width=64, height=48, bounces=2, samples=1)
+    ctxs = [_native.Context(0) for _ in range(2)]
+    try:
+        for c in ctxs:
+            c.upload(flat)
+        alone = ctxs[0].render_rows(opt, seed=0)
+        frame = torch.zeros((48, 64, 3), dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        _native.render_frame_multi(ctxs, opt, 0, frame_ptr=frame.data_ptr())
+        assert np.array_equal(frame.cpu().numpy(), alone["bgr"])
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_photon_render_reuses_the_device_scene_and_sees_edits():
+    """A second render() of an unchanged scene uploads nothing (the device starts on the frame while the host checks the
+    scene's fingerprint); an edit between two renders shows, as it does in the reference, which copies the scene on
+    every call (T3DR.py:1090)."""
+    import T3DE
+    import T3DR
+    scene = T3DE.Scene.fromJSON(scene_path("cornellScene.json"))
+    opts = {"width": 96, "height": 72, "bounces": 3, "samples": 2, "seed": 4}
+    photon = T3DR.Photon(scene, opts)
+    first = photon.render()
+    assert photon.uploads == 1
+    second = photon.render()
+    assert photon.uploads == 1 and np.array_equal(first.imageAs("np"), second.imageAs("np")) and second.rays == first.rays
+    keep = first.imageAs("np").copy()
+    third = photon.render(returnType="np")                       # buffers of earlier results are not recycled under them
+    assert np.array_equal(first.imageAs("np"), keep) and np.array_equal(third, first.imageAs("cv2"))
+    ball = next(o for o in scene.objects if o.type == "sphere")
+    ball.position = T3DE.Vec3(ball.position.x + 0.7, ball.position.y, ball.position.z)
+    moved = photon.render()
+    assert photon.uploads == 2 and not np.array_equal(moved.imageAs("np"), keep)
+    fresh = T3DR.Photon(scene, dict(opts)).render()
+    assert np.array_equal(moved.imageAs("np"), fresh.imageAs("np")) and moved.rays == fresh.rays
+    photon.options["bounces"] = 1                                # options are read on every call (explorer.py:1171)
+    assert not np.array_equal(photon.render().imageAs("np"), moved.imageAs("np"))
+    # trees that do not fit an unchecked call's buffers: the frame is rendered again, checked
+    from raytracing_amd.scene import Camera, Light, Material, Scale, Scene, Shader, Sphere, Vec3, RGB
+    s = Scene()
+    Camera(s, position=Vec3(0, 0, -4), length=30)
+    for r in (3.0, 2.6, 2.2, 1.8, 1.4, 1.0):
+        b = Sphere(s, position=Vec3(0, 0, 6))
+        b.scale = Scale(2 * r, 2 * r, 2 * r)
+        b.setShader(Shader(color=RGB(200, 220, 250), roughness=0.0, reflectivity=0.5))
+        b.material = Material(ior=1.3)
+    Light(s, position=Vec3(4, 5, -2), strength=1.0)
+    glass = T3DR.Photon(s, {"width": 24, "height": 16, "bounces": 9, "samples": 2, "seed": 5})
+    shallow = dict(glass.options, bounces=1)
+    glass.options["bounces"] = 1
+    glass.render()                                               # small buffers, scene on the device
+    glass.options["bounces"] = 9
+    deep = glass.render()                                        # starts unchecked, overflows, is rendered again
+    assert np.array_equal(deep.imageAs("np"), T3DR.Photon(s, dict(shallow, bounces=9)).render().imageAs("np"))
+
+
+def test_photon_render_on_several_gpus():
+    import T3DE
+    import T3DR
+    scene = T3DE.Scene.fromJSON(scene_path("cornellScene.json"))
+    opts = {"width": 64, "height": 48, "bounces": 2, "samples": 2, "seed": 3}
+    one = T3DR.Photon(scene, dict(opts)).render()
+    calls = []
+    multi = T3DR.Photon(scene, dict(opts, gpus=3, devices=[0, 0, 0]))
+    got = multi.render(progressCallback=lambda table, key, total: calls.append((key, table[key], total)))
+    assert np.array_equal(got.imageAs("np"), one.imageAs("np")) and got.rays == one.rays and not got.failed
+    assert calls[0] == (0, 0, 48 * 64) and calls[-1] == (0, 48 * 64 - 1, 48 * 64)
+    assert np.array_equal(multi.render(returnType="np"), one.imageAs("cv2")) and multi.uploads == 3
+    with pytest.raises(ValueError, match="factor of image height"):
+        T3DR.Photon(scene, dict(opts, gpus=5, devices=[0] * 5)).render()
+    assert isinstance(got.traces[(32, 30)][0], T3DE.TraceTreeNode)     # single-ray queries use a context of their own
+    assert multi.uploads == 4
+
+
+def test_single_ray_trees_with_many_lights_need_little_memory(gpu_ctx, oracle_mod):
+    """The tree of one pixel at 12 bounces in a scene whose 968 emissive faces are 968 lights: the work set of a
+    single ray is sized by its tree (at most 2^12 nodes a level), not by a band of rows."""
+    from raytracing_amd.flatten import flatten_scene
+    from raytracing_amd.scene import Scene
+    scene = Scene.fromJSON(scene_path("config2_suzanne.json"))
+    monkey = next(o for o in scene.objects if o.type == "mesh" and len(o.mesh.faces) > 500)
+    for sh in monkey.shaders:
+        sh.emissionStrength = 0.05
+    flat = flatten_scene(scene)
+    assert len(flat.light_strength) >= 968
+    gpu_ctx.upload(flat)
+    opt = dict(width=96, height=54, bounces=12, samples=1)
+    nodes = gpu_ctx.trace_pixel(opt, 30, 40, 0, seed=1)
+    ref = oracle_mod.render(flat, opt, seed=1, row0=40, nrows=1, want_nodes=True, node_cap=400000)
+    want = {int(n["heap"]): n for n in ref["nodes"] if (int(n["px"]), int(n["py"]), int(n["sample"])) == (30, 40, 0)}
+    assert sorted(n.heap for n in nodes) == sorted(want) and len(nodes) >= 1
+    for n in nodes:
+        assert np.allclose(list(n.color), want[n.heap]["color"], atol=0.05)

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import SCENES, flat_for
+from conftest import flat_for, scene_path
 from raytracing_amd import keyed_rng
 from raytracing_amd.flatten import flatten_scene
 from raytracing_amd.scene import RGB, Euler, Scale, Scene, Vec3
@@ -30,7 +30,7 @@ def test_apply_transforms(kat, oracle_mod):
 
 
 def test_camera_rays(kat, oracle_mod):
-    scene = Scene.fromJSON(os.path.join(SCENES, "cornellScene.json"))
+    scene = Scene.fromJSON(scene_path("cornellScene.json"))
     for e in kat["camera"]:
         scene.camera.rotation = Euler(*e["rot"])
         scene.camera.length = e["length"]
@@ -77,7 +77,7 @@ def test_bvh_and_baking(kat, oracle_mod):
             assert order == [f for leaf in e["leaves"] for f in leaf]
             assert sizes == [len(leaf) for leaf in e["leaves"]]
             # baked vertices of the flattening step == Object.setTransforms of the reference
-            scene = Scene.fromJSON(os.path.join(SCENES, "cornellScene.json"))
+            scene = Scene.fromJSON(scene_path("cornellScene.json"))
             obj = scene.objects[e["object"]]
             baked = np.array(e["baked_vertices"])
             faces = np.array(obj.mesh.faces)

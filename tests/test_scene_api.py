@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import SCENES
+from conftest import scene_path
 from raytracing_amd.flatten import flatten_scene, make_opts
 from raytracing_amd.scene import (RGB, Camera, Cube, Euler, Light, Material, Mesh, Object, Ray, Scale, Scene, Shader,
                                   Sphere, Vec3)
@@ -24,7 +24,7 @@ def test_drop_in_module_names():
 
 
 def test_cornell_json_loads_unchanged():
-    scene = Scene.fromJSON(os.path.join(SCENES, "cornellScene.json"))
+    scene = Scene.fromJSON(scene_path("cornellScene.json"))
     assert [o.type for o in scene.objects] == ["camera", "mesh", "mesh", "sphere"]   # bound camera first
     assert scene.camera is scene.objects[0] and scene.camera.length == 20.0
     box = scene.objects[1]
@@ -33,7 +33,7 @@ def test_cornell_json_loads_unchanged():
     idx = box.shaderIndices
     assert idx[48] == idx[49] == 2 and idx[28] == idx[29] == 3 and idx[26] == idx[27] == 4
     assert all(i == 1 for k, i in enumerate(idx) if k not in (26, 27, 28, 29, 48, 49))
-    old = Scene.fromJSON(os.path.join(SCENES, "cornellScene2.json"))                # older schema
+    old = Scene.fromJSON(scene_path("cornellScene2.json"))                # older schema
     assert old.camera.length == 1.0 and len(old.objects) == 4
 
 
@@ -41,12 +41,12 @@ def test_stl_import_reproduces_reference_mesh():
     """cornellbox.stl -> swap y/z, reverse winding, rotate 90 degrees about y == the Box of cornellScene.json,
     face by face, exactly."""
     built = flatten_scene(cornell_scene(with_light=False))
-    loaded = flatten_scene(Scene.fromJSON(os.path.join(SCENES, "cornellScene.json")))
+    loaded = flatten_scene(Scene.fromJSON(scene_path("cornellScene.json")))
     assert np.array_equal(built.tri_verts, loaded.tri_verts)
     assert np.array_equal(built.shader_rough[built.tri_shader], loaded.shader_rough[loaded.tri_shader])
     assert np.array_equal(built.shader_emis[built.tri_shader], loaded.shader_emis[loaded.tri_shader])
     for name in ("config2_cornell_light.json", "config2_suzanne.json"):
-        ref = flatten_scene(Scene.fromJSON(os.path.join(SCENES, name)))
+        ref = flatten_scene(Scene.fromJSON(scene_path(name)))
         mine = flatten_scene(cornell_scene(with_light=True, suzanne="suzanne" in name))
         assert np.array_equal(mine.tri_verts, ref.tri_verts)
         assert np.array_equal(mine.light_pos, ref.light_pos)
@@ -196,7 +196,7 @@ def test_flat_scene_digest_tracks_every_input():
     """Equal flattenings have equal digests; moving an object, a shader value or the camera changes it."""
     import T3DE
     from raytracing_amd.flatten import flatten_scene
-    path = os.path.join(SCENES, "cornellScene.json")
+    path = scene_path("cornellScene.json")
     a, b = T3DE.Scene.fromJSON(path), T3DE.Scene.fromJSON(path)
     base = flatten_scene(a).digest()
     assert flatten_scene(b).digest() == base and len(base) == 16
