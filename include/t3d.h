@@ -209,6 +209,25 @@ int t3d_host_alloc(size_t bytes, void** out);
 int t3d_host_free(void* p);
 
 /*
+ * t3d_render_rows_device for callers that cannot allocate device memory at the time of the call: code running under
+ * HIP graph capture, tight serving loops, harnesses that forbid it.  Same arguments, same pixels.  It calls no
+ * hipMalloc / hipFree and builds no launch graph: every work buffer (ray queues, node arrays, light intensities,
+ * sample colours, the hit list of the LBVH path) is a piece of ONE array of T3D_STATIC_SCRATCH_MIB MiB that is part
+ * of the library's code object, exists once per GPU from the moment the library is loaded there until the process
+ * ends, and is shared by every context and every call on that GPU: calls that overlap on one GPU race (one at a time,
+ * whatever their streams).  The frame is cut into as many bands of rows as the array takes (1920x1080 at 4 bounces
+ * and 3 lights: 12 bands).  T3D_E_CAPACITY with a message naming the limit when even one image row does not fit
+ * (very wide rows, thousands of lights, deep trees); with `stats` a band whose trees overflow is halved and traced
+ * again, without `stats` the overflow is reported by the next call as for t3d_render_rows_device.  Nothing in the
+ * array needs clearing between calls: the queue counters (in the context, allocated by t3d_create) say which entries
+ * are valid.  No counterpart in the reference.
+ */
+#define T3D_STATIC_SCRATCH_MIB 128
+int t3d_render_rows_device_static(t3d_ctx* ctx, const t3d_opts* opts, int row0, int nrows, uint8_t* bgr_device,
+                                  float* radiance_device, int32_t* primary_device, float* primary_t_device,
+                                  void* stream, t3d_stats* stats);
+
+/*
  * Trace one pixel sample and return its tree (Photon.trace + computeColor for one initial ray;
  * serves Rendered.traces[(x, y)][sample] lazily, T3DR.py:1210-1216).  Returns the number of
  * nodes written (>= 0), nodes in depth-first order with the bounce child before the transmit

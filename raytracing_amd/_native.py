@@ -17,7 +17,8 @@ ABI_VERSION = 3
 SYMBOLS = ("t3d_abi_version", "t3d_device_count", "t3d_create", "t3d_destroy", "t3d_last_error",
            "t3d_upload_scene", "t3d_render_rows", "t3d_render_rows_device", "t3d_trace_pixel", "t3d_trace_ray",
            "t3d_closest_hits", "t3d_last_call_stats", "t3d_set_timing", "t3d_set_accel", "t3d_set_rounds", "t3d_set_cancel",
-           "t3d_render_rows_async", "t3d_host_alloc", "t3d_host_free", "t3d_render_frame_multi")
+           "t3d_render_rows_async", "t3d_host_alloc", "t3d_host_free", "t3d_render_frame_multi",
+           "t3d_render_rows_device_static")
 
 
 class NativeError(RuntimeError):
@@ -94,6 +95,8 @@ def load():
     lib.t3d_render_rows_device.restype = C.c_int
     lib.t3d_render_rows_device.argtypes = [C.c_void_p, P(Opts), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p, P(Stats)]
+    lib.t3d_render_rows_device_static.restype = C.c_int
+    lib.t3d_render_rows_device_static.argtypes = lib.t3d_render_rows_device.argtypes
     lib.t3d_trace_pixel.restype = C.c_int
     lib.t3d_trace_pixel.argtypes = [C.c_void_p, P(Opts), C.c_int, C.c_int, C.c_int, P(Node), C.c_int]
     lib.t3d_trace_ray.restype = C.c_int
@@ -248,14 +251,16 @@ class Context:
 
     def render_rows_device(self, options: dict, seed: int, row0: int, nrows: int, bgr_ptr: int, radiance_ptr: int = 0,
                            primary_ptr: int = 0, primary_t_ptr: int = 0, stream: int = 0, want_stats=True,
-                           row_stride: int = 1):
-        """Outputs go to caller-owned device memory (raw addresses, e.g. ``tensor.data_ptr()``)."""
+                           row_stride: int = 1, static=False):
+        """Outputs go to caller-owned device memory (raw addresses, e.g. ``tensor.data_ptr()``).  ``static``: through
+        ``t3d_render_rows_device_static``, which allocates nothing (work buffers in the library's per-GPU static array)."""
         opts = make_opts(options, seed, row_stride=row_stride)
         stats = Stats() if want_stats else None
-        self._check(self._lib.t3d_render_rows_device(
+        fn = self._lib.t3d_render_rows_device_static if static else self._lib.t3d_render_rows_device
+        self._check(fn(
             self._h, C.byref(opts), row0, nrows, C.c_void_p(bgr_ptr), C.c_void_p(radiance_ptr or None),
             C.c_void_p(primary_ptr or None), C.c_void_p(primary_t_ptr or None), C.c_void_p(stream or None),
-            C.byref(stats) if stats is not None else None), "t3d_render_rows_device")
+            C.byref(stats) if stats is not None else None), "t3d_render_rows_device_static" if static else "t3d_render_rows_device")
         return stats.as_dict() if stats is not None else None
 
     def last_call_stats(self):

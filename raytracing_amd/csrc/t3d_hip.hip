@@ -45,6 +45,7 @@
 
 #include <cmath>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <tuple>
@@ -1293,6 +1294,30 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_closest(DevScene sc, GEO_PARAMS, 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// Work buffers for callers that must not allocate (t3d_render_rows_device_static): one array per GPU, part of the
+// library's code object, alive from the moment the library is loaded on a device until the process ends.  In host code
+// the array's NAME is only a stand-in; the address of a device's copy comes from hipGetSymbolAddress with that device
+// current (static_scratch_for, called by t3d_create) and that pointer is what every launch and memset is given.
+#define T3D_STATIC_SCRATCH_BYTES ((size_t)128 << 20)
+static __device__ __align__(256) unsigned char t3d_static_scratch[T3D_STATIC_SCRATCH_BYTES];
+#define T3D_MAX_DEVICES 64
+static unsigned char* g_static_scratch[T3D_MAX_DEVICES];   // per device: address of its copy of the array, null until asked for
+static std::mutex g_static_scratch_mutex;
+
+// Address of the CURRENT device's copy (the caller has made `device` current); null with *err set on failure.
+static unsigned char* static_scratch_for(int device, hipError_t* err) {
+    *err = hipSuccess;
+    if (device < 0 || device >= T3D_MAX_DEVICES) { *err = hipErrorInvalidDevice; return nullptr; }
+    std::lock_guard<std::mutex> lock(g_static_scratch_mutex);
+    if (!g_static_scratch[device]) {
+        void* p = nullptr;
+        *err = hipGetSymbolAddress(&p, HIP_SYMBOL(t3d_static_scratch));
+        if (*err != hipSuccess) return nullptr;
+        g_static_scratch[device] = (unsigned char*)p;
+    }
+    return g_static_scratch[device];
+}
+
 // Work buffers of one render call (a band of rows, or the tree of a single ray).
 struct Work {
     size_t cap = 0;      // entries per level in the ray queues and node arrays
@@ -1366,11 +1391,14 @@ struct t3d_ctx {
     int* h_sticky = nullptr;
     size_t async_min_cap = 0;       // entries per level that asynchronous calls start with: twice what the last one that overflowed had
     size_t last_async_cap = 0;      // entries per level of the most recent asynchronous band
+    bool last_async_static = false; // ... which was a band of t3d_render_rows_device_static
+    int static_async_factor = 2;    // rays per sample and level that asynchronous static calls provide for: doubled after an overflow
     // cancellation (Photon.render's cancelCallback, T3DR.py:1227-1237)
     int (*cancel_cb)(void*) = nullptr; void* cancel_user = nullptr;
     // t3d_closest_hits: pinned staging the kernel reads its rays from and writes its answers to
     void* h_pick = nullptr; size_t pick_alloc = 0;
     t3d_node* d_dbg = nullptr; int dbg_alloc = 0;   // node records of a single ray's tree (t3d_trace_pixel / t3d_trace_ray)
+    unsigned char* static_scratch = nullptr;        // this device's copy of t3d_static_scratch (t3d_render_rows_device_static)
     bool counters_on_host = false;   // h_cnt holds (or is about to receive) the counters of the most recent band
 };
 
@@ -1426,6 +1454,8 @@ extern "C" int t3d_create(int device, t3d_ctx** out) {
         hipHostMalloc((void**)&c->h_sticky, 64, hipHostMallocDefault) != hipSuccess)
         return fail(T3D_E_NOMEM, "counter allocation failed");
     c->h_sticky[0] = c->h_sticky[1] = 0;
+    c->static_scratch = static_scratch_for(device, &e);   // the device is current
+    if (!c->static_scratch) return fail(T3D_E_DEVICE, std::string("address of the static work array: ") + hipGetErrorString(e));
     *out = c;
     return T3D_OK;
 }
@@ -2067,7 +2097,7 @@ issued:
     c->last_events = events;
     c->last_levels = levels; c->last_n0 = n0; c->last_lights = o->lights; c->last_launches = launches; c->last_stream = st;
     c->last_valid = true;
-    if (!stats && !single) { c->last_async_cap = cap_used; return T3D_OK; }  // asynchronous use: an overflow raises the context's sticky words, see t3d_ctx
+    if (!stats && !single) { c->last_async_cap = cap_used; c->last_async_static = fixed_work; return T3D_OK; }  // asynchronous use: an overflow raises the context's sticky words, see t3d_ctx
     HIPCHK(c, hipStreamSynchronize(st));
     if (c->h_cnt->overflow) { c->h_sticky[0] = 0; return T3D_E_CAPACITY; }   // seen and dealt with by the caller: not left standing
     if (c->h_cnt->bvh_stack_overflow) { c->h_sticky[1] = 0; c->err = "LBVH traversal stack overflow"; return T3D_E_DEVICE; }
@@ -2084,7 +2114,8 @@ static int take_sticky(t3d_ctx* c) {
     }
     if (c->h_sticky[0]) {
         c->h_sticky[0] = 0;
-        c->async_min_cap = 2 * (c->last_async_cap > c->async_min_cap ? c->last_async_cap : c->async_min_cap);
+        if (c->last_async_static) { if (c->static_async_factor < (1 << T3D_MAX_BOUNCES)) c->static_async_factor *= 2; }
+        else c->async_min_cap = 2 * (c->last_async_cap > c->async_min_cap ? c->last_async_cap : c->async_min_cap);
         c->err = "an earlier asynchronous render call overflowed its node buffers (its output is invalid); asynchronous calls use larger buffers from now on";
         return T3D_E_CAPACITY;
     }
@@ -2137,6 +2168,100 @@ extern "C" int t3d_render_rows_device(t3d_ctx* c, const t3d_opts* o, int row0, i
                 continue;
             }
             if (rc) { if (rc == T3D_E_CAPACITY) c->err = "trace tree does not fit the node buffers"; return rc; }
+            if (stats) {
+                uint64_t* dst = &stats->rays_api; const uint64_t* src = &band_stats.rays_api;
+                for (int k = 0; k < T3D_STATS_N_COUNTERS; ++k) dst[k] += src[k];
+                stats->ms_device += band_stats.ms_device; stats->ms_k_level += band_stats.ms_k_level;
+                stats->ms_resolve += band_stats.ms_resolve;
+                for (int k = 0; k < T3D_STATS_MAX_LEVELS; ++k) {
+                    stats->level_rays[k] += band_stats.level_rays[k]; stats->level_nodes[k] += band_stats.level_nodes[k];
+                    stats->level_ms[k] += band_stats.level_ms[k];
+                }
+                stats->bvh_deep_pushes += band_stats.bvh_deep_pushes;
+            }
+            break;
+        }
+        r += nb;
+    }
+    return T3D_OK;
+}
+
+// Lays the work buffers of a band out in `base` (`bytes` long); false if they do not fit.
+static bool carve_work(unsigned char* base, size_t bytes, size_t cap, int levels, size_t n0, int n_lights, bool bvh, Work& w) {
+    size_t off = 0;
+    auto take = [&](size_t n) -> unsigned char* {
+        unsigned char* p = base + off;
+        off += (n + 255) / 256 * 256;
+        return off <= bytes ? p : nullptr;
+    };
+    const size_t lv = (size_t)levels, L = (size_t)(n_lights > 0 ? n_lights : 1);
+    w = Work{};
+    bool ok = true;
+    auto get = [&](auto*& dst, size_t n) { dst = (std::remove_reference_t<decltype(dst)>)take(n); ok = ok && dst != nullptr; };
+    get(w.rays[0], sizeof(RayRec) * cap); get(w.rays[1], sizeof(RayRec) * cap);
+    get(w.pool.parent, sizeof(int) * cap * lv); get(w.pool.c, sizeof(float4) * cap * lv); get(w.pool.d, sizeof(float4) * cap * lv);
+    get(w.pool.li, sizeof(float) * cap * lv * L);
+    if (bvh) {
+        get(w.hits, sizeof(uint2) * cap);
+        for (int k = 0; k < 2; ++k) { get(w.src_a[k], sizeof(float4) * cap); get(w.src_b[k], sizeof(float4) * cap); }
+    }
+    get(w.sample_color, sizeof(float4) * n0);
+    if (!ok) { w = Work{}; return false; }
+    w.cap = cap; w.levels = levels; w.li_lights = n_lights; w.n0 = n0;
+    return true;
+}
+
+// t3d_render_rows_device for callers that cannot allocate: no hipMalloc / hipFree, no launch graph; every work buffer
+// is a piece of the device's static array, the frame is cut into as many bands as that takes.
+extern "C" int t3d_render_rows_device_static(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, uint8_t* bgr_device,
+                                             float* radiance_device, int32_t* primary_device, float* primary_t_device,
+                                             void* stream, t3d_stats* stats) {
+    int rc = check_opts(c, o, row0, nrows);
+    if (rc) return rc;
+    if (!bgr_device) { c->err = "bgr output is required"; return T3D_E_INVALID; }
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = take_sticky(c)) != T3D_OK) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    if (stats) memset(stats, 0, sizeof *stats);
+    const int S = o->bounces > 1 ? o->samples : 1;
+    const int levels = o->bounces + 1;
+    const size_t row_samples = (size_t)o->width * S;
+    auto cap_for = [&](size_t n0, int factor) {
+        size_t cap = n0 * (size_t)factor;
+        if (cap < 64 * 1024) cap = 64 * 1024;
+        return (cap + (size_t)T3D_SHARDS * 64 - 1) / ((size_t)T3D_SHARDS * 64) * ((size_t)T3D_SHARDS * 64);
+    };
+    Work w;
+    auto fits = [&](int rows, int factor) {
+        return carve_work(c->static_scratch, T3D_STATIC_SCRATCH_BYTES, cap_for((size_t)rows * row_samples, factor), levels,
+                          (size_t)rows * row_samples, c->sc.n_lights, c->use_bvh, w);
+    };
+    // a call without stats cannot see an overflow and try again: it starts from what earlier overflows have taught
+    const int factor0 = stats ? 2 : c->static_async_factor;
+    if (!fits(1, factor0)) {
+        c->err = "t3d_render_rows_device_static: one image row of this width, depth and light count does not fit the static work array (128 MiB)";
+        return T3D_E_CAPACITY;
+    }
+    int band = 1;   // the largest number of rows whose optimistic working set (two rays per sample and level) fits
+    for (int lo = 1, hi = nrows; lo <= hi;) { const int mid = lo + (hi - lo) / 2; if (fits(mid, factor0)) { band = mid; lo = mid + 1; } else hi = mid - 1; }
+    for (int r = 0; r < nrows;) {
+        if (c->cancel_cb && c->cancel_cb(c->cancel_user)) { c->last_valid = false; c->err = "render cancelled by the caller's cancel callback"; return T3D_E_CANCELLED; }
+        int nb = band < nrows - r ? band : nrows - r;
+        int factor = factor0;
+        const size_t off = (size_t)r * o->width;
+        for (;;) {
+            if (!fits(nb, factor)) { c->err = "t3d_render_rows_device_static: trace tree does not fit the static work array (128 MiB)"; return T3D_E_CAPACITY; }
+            t3d_stats band_stats{};
+            rc = render_band(c, w, o, row0 + r * (o->row_stride > 1 ? o->row_stride : 1), nb, factor, bgr_device + 3 * off,
+                             radiance_device ? radiance_device + 3 * off : nullptr, primary_device ? primary_device + 2 * off : nullptr,
+                             primary_t_device ? primary_t_device + off : nullptr, st, stats ? &band_stats : nullptr, nullptr, nullptr, 0, true);
+            if (rc == T3D_E_CAPACITY) {
+                // only a call with stats gets here (it has waited for the band): fewer rows, and for a single row a larger factor
+                if (nb > 1) { nb = (nb + 1) / 2; continue; }
+                factor *= 2;
+                continue;
+            }
+            if (rc) return rc;
             if (stats) {
                 uint64_t* dst = &stats->rays_api; const uint64_t* src = &band_stats.rays_api;
                 for (int k = 0; k < T3D_STATS_N_COUNTERS; ++k) dst[k] += src[k];
