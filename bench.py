@@ -160,7 +160,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    first_stats, frame = step(True)  # checked step: counters + capacity
+    # checked steps, one per chain: counters, and work buffers grown to what this scene's trace trees need
+    first_stats, frame = step(True)
+    for _ in range(F - 1):
+        step(True)
     for c in ctxs:
         c.set_timing(False)
     # untimed steps: the warm-up asked for, and at least as many as every chain needs to reach its steady state (a

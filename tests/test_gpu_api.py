@@ -9,23 +9,32 @@ from test_gpu_parity import nested_glass_scene
 pytestmark = pytest.mark.gpu
 
 
-def test_async_overflow_is_reported_once_and_buffers_grow(monkeypatch):
+@pytest.mark.parametrize("path", ["frame", "per_level", "lbvh"])
+def test_async_overflow_is_reported_once_and_buffers_grow(monkeypatch, path):
     """An asynchronous call (no stats) whose trace trees outgrow the work buffers cannot say so itself.  The overflow
     stays on record -- also when the frame was cut into several bands, whose counters replace each other -- until the
     next look: t3d_last_call_stats, or the next render call, returns T3D_E_CAPACITY once, and asynchronous calls start
-    with larger buffers from then on."""
+    with larger buffers from then on.  On all three ways a band is traced: one launch per band (brute force), a launch
+    per tree level (brute force, as the static entry point and single rays do it), the LBVH kernels."""
     from raytracing_amd import _native
     flat = nested_glass_scene()
     opt = dict(width=24, height=16, bounces=9, samples=2)
-    monkeypatch.setenv("T3D_MEM_BUDGET_MB", "1")       # several bands per frame
-    ctx = _native.Context(0)
+    monkeypatch.setenv("T3D_MEM_BUDGET_MB", "1")       # several bands per frame where memory grows with the band
+    if path == "per_level":
+        monkeypatch.setenv("T3D_PER_LEVEL", "1")
+
+    def context():
+        c = _native.Context(0)
+        c.set_accel("lbvh" if path == "lbvh" else "brute")
+        c.upload(flat)
+        return c
+
+    ctx = context()
     try:
-        ctx.upload(flat)
         want = ctx.render_rows(opt, seed=5)                      # checked call: grows per band as needed
-        assert want["stats"]["launches"] > 30
-        fresh = _native.Context(0)                               # a context whose buffers have not grown yet
+        assert path == "frame" or want["stats"]["launches"] > 30
+        fresh = context()                                        # a context whose buffers have not grown yet
         try:
-            fresh.upload(flat)
             img = _native.pinned_image((16, 24, 3))
             seen = 0
             for attempt in range(12):
@@ -39,9 +48,8 @@ def test_async_overflow_is_reported_once_and_buffers_grow(monkeypatch):
             assert seen >= 1, "the first asynchronous frame cannot have fitted buffers sized for two rays per sample"
             assert attempt < 11 and np.array_equal(img, want["bgr"])
             # the overflow of a call nobody asked about is reported by the next call instead
-            small = _native.Context(0)
+            small = context()
             try:
-                small.upload(flat)
                 small.render_rows_async(opt, 5, 0, 16, img)
                 import time
                 deadline = time.time() + 5.0
@@ -57,36 +65,56 @@ def test_async_overflow_is_reported_once_and_buffers_grow(monkeypatch):
         ctx.close()
 
 
-def test_cancel_stops_between_levels_and_the_context_recovers(gpu_ctx):
+@pytest.mark.parametrize("path", ["frame", "per_level", "lbvh"])
+def test_cancel_stops_inside_a_render_and_the_context_recovers(monkeypatch, path):
+    """The cancel callback is asked before every band and after every launch group that ends a tree level (brute-force
+    scenes traced with one launch per band: after that launch; a large frame is cut into bands of about a million
+    samples while a callback is installed)."""
     from raytracing_amd import _native
+    if path == "per_level":
+        monkeypatch.setenv("T3D_PER_LEVEL", "1")
     flat = flat_for("config2_cornell_light.json")
-    gpu_ctx.upload(flat)
-    opt = dict(width=160, height=96, bounces=4, samples=2)
-    want = gpu_ctx.render_rows(opt, seed=1)
-    polls = []
+    ctx = _native.Context(0)
+    try:
+        ctx.set_accel("lbvh" if path == "lbvh" else "brute")
+        ctx.upload(flat)
+        opt = dict(width=160, height=96, bounces=4, samples=2)
+        want = ctx.render_rows(opt, seed=1)
+        polls = []
 
-    def stop_at(k):
-        def poll():
-            polls.append(1)
-            return len(polls) > k
-        return poll
+        def stop_at(k):
+            def poll():
+                polls.append(1)
+                return len(polls) > k
+            return poll
 
-    for k in (0, 1, 3):          # before the band, after its first level, after its third
+        per_band = 2 if path == "frame" else 6           # before the band, then after the frame launch / after each of 5 levels
+        for k in ((0, 1) if path == "frame" else (0, 1, 3)):
+            polls.clear()
+            ctx.set_cancel(stop_at(k))
+            with pytest.raises(_native.Cancelled):
+                ctx.render_rows(opt, seed=1)
+            assert len(polls) == k + 1
+            with pytest.raises(_native.NativeError):                 # a cancelled call has no statistics
+                ctx.last_call_stats()
         polls.clear()
-        gpu_ctx.set_cancel(stop_at(k))
-        with pytest.raises(_native.Cancelled):
-            gpu_ctx.render_rows(opt, seed=1)
-        assert len(polls) == k + 1
-        with pytest.raises(_native.NativeError):                 # a cancelled call has no statistics
-            gpu_ctx.last_call_stats()
-    polls.clear()
-    gpu_ctx.set_cancel(lambda: polls.append(1) and False)        # asked, never stops: 1 band + 5 levels
-    got = gpu_ctx.render_rows(opt, seed=1)
-    assert len(polls) == 6 and np.array_equal(got["bgr"], want["bgr"]) and got["stats"]["queries"] == want["stats"]["queries"]
-    gpu_ctx.set_cancel(None)
-    polls.clear()
-    again = gpu_ctx.render_rows(opt, seed=1)
-    assert not polls and np.array_equal(again["bgr"], want["bgr"]) and again["stats"]["queries"] == want["stats"]["queries"]
+        ctx.set_cancel(lambda: polls.append(1) and False)            # asked, never stops
+        got = ctx.render_rows(opt, seed=1)
+        assert len(polls) == per_band and np.array_equal(got["bgr"], want["bgr"]) and got["stats"]["queries"] == want["stats"]["queries"]
+        if path == "frame":
+            # a frame of 2.4 M samples is cut into bands while somebody may want to stop it
+            big = dict(width=1280, height=960, bounces=1, samples=1)
+            polls.clear()
+            whole = ctx.render_rows(big, seed=1)
+            assert len(polls) >= 4
+            ctx.set_cancel(None)
+            assert np.array_equal(ctx.render_rows(big, seed=1)["bgr"], whole["bgr"])
+        ctx.set_cancel(None)
+        polls.clear()
+        again = ctx.render_rows(opt, seed=1)
+        assert not polls and np.array_equal(again["bgr"], want["bgr"]) and again["stats"]["queries"] == want["stats"]["queries"]
+    finally:
+        ctx.close()
 
 
 @pytest.mark.parametrize("accel", ["brute", "lbvh"])

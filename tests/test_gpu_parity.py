@@ -227,17 +227,27 @@ def test_maximum_bounces_and_growing_trees(gpu_ctx, oracle_mod):
     check_growing_trees(gpu_ctx, oracle_mod)
 
 
-def test_small_memory_budget_splits_the_frame(gpu_ctx, monkeypatch):
+@pytest.mark.parametrize("path", ["per_level", "lbvh"])
+def test_small_memory_budget_splits_the_frame(gpu_ctx, monkeypatch, path):
     """With a working-set budget of 1 MiB the frame is cut into bands of a few rows, and bands whose trees outgrow the
-    budget are halved: same pixels and the same counts as the frame in one piece."""
+    budget are halved: same pixels and the same counts as the frame in one piece.  (On the two paths whose work memory
+    grows with the band: a launch per tree level, and the LBVH kernels.)"""
     from raytracing_amd import _native
     flat = nested_glass_scene()
     opt = dict(width=24, height=16, bounces=9, samples=2)
-    gpu_ctx.upload(flat)
-    whole = gpu_ctx.render_rows(opt, seed=5, want_radiance=True, want_primary=True)
+    roomy = _native.Context(0)          # the same path with the default budget: the frame in one piece
+    try:
+        roomy.set_accel("lbvh" if path == "lbvh" else "brute")
+        roomy.upload(flat)
+        whole = roomy.render_rows(opt, seed=5, want_radiance=True, want_primary=True)
+    finally:
+        roomy.close()
     monkeypatch.setenv("T3D_MEM_BUDGET_MB", "1")
+    if path == "per_level":
+        monkeypatch.setenv("T3D_PER_LEVEL", "1")
     small = _native.Context(0)
     try:
+        small.set_accel("lbvh" if path == "lbvh" else "brute")
         small.upload(flat)
         cut = small.render_rows(opt, seed=5, want_radiance=True, want_primary=True)
         part = small.render_rows(opt, seed=5, row0=5, nrows=7)
