@@ -138,9 +138,6 @@ struct RenderParams {
     int tiled;              // level 0 walks the band in 16 x 8 pixel tiles (width % 16 == 0, rows % 8 == 0)
     float ray_o[3], ray_d[3], ray_ior;  // single == 2: the initial ray (unit direction) ...
     int ray_obj;                        // ... and the object it travels inside (-1 none)
-    int unit;        // k_frame: primary samples per unit of work
-    int unit_stride; // k_frame: the n-th unit a shard hands out is number (n * unit_stride) mod (units per shard) of its list: neighbours in
-                     // time are far apart in the image, so the heavy parts of a picture are spread over waves and over the launch
     int shard_bits;  // log2 of the number of queue shards in use: 6 for image bands, 0 for the tree of a single ray
     int* sticky;     // two host-visible words (pinned memory): [0] set when a queue or node array overflows, [1] when a
                      // traversal stack does; see t3d_ctx
@@ -182,8 +179,6 @@ struct Counters {
     int bvh_stack_overflow;
     int pad_[13];
     unsigned long long bvh_stat[T3D_SHARDS][8];  // per shard: nodes visited, triangle tests, sphere tests (one 64-byte line each)
-    PaddedCount unit_next[T3D_SHARDS];           // k_frame: units of work handed out so far, per shard
-    unsigned long long frame_dbg[8];             // k_frame: earliest wave start (complemented), latest start, latest end (100 MHz ticks)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -350,12 +345,9 @@ __device__ __forceinline__ bool ray_meets_scene_box(const DevGeo& geo, V3 o, V3 
     return tn <= tf;
 }
 
-// lights: Light objects are tested at all (wave-uniform); see0 / see1: this lane's ray may hit them (primary rays traced
-// with options['lights'] off may not, T3DR.py:666-687)
 template <bool BOX_FIRST = false, bool NO_CULL = false>
 __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0, V3 d0, V3 o1, V3 d1,
-                                             bool lights, bool back_cull0, bool back_cull1, Hit& out0, Hit& out1,
-                                             bool see0 = true, bool see1 = true) {
+                                             bool lights, bool back_cull0, bool back_cull1, Hit& out0, Hit& out1) {
     const uint32_t INF_BITS = 0x7f800000u;
     const f2 ox = {o0.x, o1.x}, oy = {o0.y, o1.y}, oz = {o0.z, o1.z};
     const f2 dx = {d0.x, d1.x}, dy = {d0.y, d1.y}, dz = {d0.z, d1.z};
@@ -392,7 +384,7 @@ __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0
         {
             const bool front = t1.x > 0.0f;
             const bool inside = (!front) & (t2.x > 0.0f) & (!back_cull0) & (sp.is_light == 0);
-            const bool ok = (disc.x >= 0.0f) & (front | inside) & (see0 | (sp.is_light == 0));
+            const bool ok = (disc.x >= 0.0f) & (front | inside);
             const uint32_t tt = ok ? __float_as_uint(front ? t1.x : t2.x) : INF_BITS;
             const bool closer = tt < best0;
             best0 = closer ? tt : best0; prim0 = closer ? n_tris + s : prim0; back0 = closer ? (front ? 0 : 1) : back0;
@@ -400,7 +392,7 @@ __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0
         {
             const bool front = t1.y > 0.0f;
             const bool inside = (!front) & (t2.y > 0.0f) & (!back_cull1) & (sp.is_light == 0);
-            const bool ok = (disc.y >= 0.0f) & (front | inside) & (see1 | (sp.is_light == 0));
+            const bool ok = (disc.y >= 0.0f) & (front | inside);
             const uint32_t tt = ok ? __float_as_uint(front ? t1.y : t2.y) : INF_BITS;
             const bool closer = tt < best1;
             best1 = closer ? tt : best1; prim1 = closer ? n_tris + s : prim1; back1 = closer ? (front ? 0 : 1) : back1;
@@ -1066,402 +1058,6 @@ __global__ __launch_bounds__(T3D_BLOCK, 4) void k_level(DevScene sc, GEO_PARAMS,
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_frame: a whole band of rows in ONE launch (scenes traced by brute force).
-//
-// Pixels are independent, so nothing forces the rays of one tree level to meet in a queue that other waves read.
-// Here every wave works alone from the camera ray to the pixel, and never runs a round that is not full while there
-// is work left in the band:
-//   * a trace round takes the (up to 128) rays at the head of the wave's own ring in global memory -- bounce and
-//     transmit rays of any level, of any of the wave's units; the level of a ray is the position of the highest bit
-//     of its heap index -- and fills the lanes that are left with primary rays;
-//   * primary rays come from UNITS of 64 samples (half a 16 x 8 pixel tile) that the wave takes from its shard's
-//     counter, one atomic per unit, whenever it has lanes to fill: a wave whose units turn out heavy (glass: a tree
-//     of up to 2^(bounces+1) - 1 nodes per sample) simply takes fewer of them, which is all the load balancing there
-//     is.  Camera rays that miss the scene's bounding box are answered at once (ambient) and never enter a round;
-//   * shadow rounds run from the LDS ring of the wave's new nodes as in k_level.
-// A unit owns one of T3D_SLOTS node regions of the wave.  When its last ray and its last shadow ray are done, the wave
-// resolves the unit's colours, deepest level first, stores the pixels and frees the region.
-//
-// What this removes, compared with one k_level launch per level and one k_resolve launch per level: every queue
-// atomic, every level boundary (a launch that drains while the next one fills), the ten launches of a frame; and the
-// work memory no longer grows with the image, only with the number of resident waves.
-// ------------------------------------------------------------------------------------------------
-#define T3D_SLOTS 32
-#define T3D_UNIT 16         // samples per unit: one row of a 16 x 8 pixel tile
-#define T3D_PRIM_LIST 192   // camera rays waiting for a lane: fewer than 128 before units are taken, which adds at most 64
-struct WavePool {
-    RayRec* q;       // [waves][q_cap]  ring of queued rays (q_cap: a power of two)
-    float4* c;       // [waves][n_cap]  node records, as in NodePool; n_cap = T3D_SLOTS regions of 1 << slot_shift nodes ...
-    float4* d;       //                 ... with d.w = shader | spawned << 22 | level << 24 | side << 30
-    int* parent;     //                 parent node (index in the same array) or, for level 0, the pixel sample
-    float* li;       // [waves][n_cap][L]
-    int q_cap, n_cap, slot_shift;
-};
-#define T3D_META_SHADER_BITS 22
-#define T3D_FRAME_MAX_SAMPLES (1 << 26)   // a waiting camera ray is its sample number (26 bits) and its unit's region (5 bits) in one word
-
-__global__ __launch_bounds__(T3D_BLOCK, 4) void k_frame(DevScene sc, GEO_PARAMS, RenderParams rp, WavePool wp, Counters* cnt, TraceOut out,
-                                                     uint4* __restrict__ zero, int n_zero) {
-    constexpr int RING = T3D_RING;
-    constexpr int N_STAT = 2 * T3D_STATS_MAX_LEVELS + 4;
-    __shared__ float4 ring_a_all[T3D_WAVES][RING];  // P.xyz, roughness
-    __shared__ float4 ring_b_all[T3D_WAVES][RING];  // unit normal, int bits: node index in the wave's array
-    __shared__ int stat_all[T3D_WAVES][N_STAT];     // per level: rays traced, nodes shaded; rounds and their filled slots
-    // per unit in flight: rays waiting, queued or being traced; nodes so far; value of ring_nodes after its latest node; in use
-    __shared__ int slot_all[T3D_WAVES][4][T3D_SLOTS];
-    __shared__ int prim_all[T3D_WAVES][T3D_PRIM_LIST];
-    // this launch is the last one of its band that touches counters: it clears the set of the NEXT band (see k_resolve)
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_zero; i += gridDim.x * blockDim.x) zero[i] = make_uint4(0u, 0u, 0u, 0u);
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const int gw = blockIdx.x * T3D_WAVES + wid;     // global wave id
-    const int shard = gw & (T3D_SHARDS - 1);
-    const int L = sc.n_lights;
-    const float inv_L = 1.0f / (float)(L > 0 ? L : 1);
-    float4* ring_a = ring_a_all[wid];
-    float4* ring_b = ring_b_all[wid];
-    int* stat = stat_all[wid];
-    int* s_live = slot_all[wid][0];
-    int* s_nn = slot_all[wid][1];
-    int* s_ring_end = slot_all[wid][2];
-    int* s_busy = slot_all[wid][3];
-    int* prim_list = prim_all[wid];
-    if (lane < N_STAT) stat[lane] = 0;
-    if (lane < T3D_SLOTS) { s_live[lane] = 0; s_nn[lane] = 0; s_ring_end[lane] = 0; s_busy[lane] = 0; }
-    RayRec* __restrict__ q = wp.q + (size_t)gw * wp.q_cap;
-    float4* __restrict__ nc = wp.c + (size_t)gw * wp.n_cap;
-    float4* __restrict__ nd = wp.d + (size_t)gw * wp.n_cap;
-    int* __restrict__ nparent = wp.parent + (size_t)gw * wp.n_cap;
-    float* __restrict__ nli = wp.li + (size_t)gw * wp.n_cap * (L > 0 ? L : 1);
-    const int q_mask = wp.q_cap - 1;
-    const int slot_shift = wp.slot_shift, slot_cap = 1 << wp.slot_shift;
-    const int n_units = (rp.n0 + T3D_UNIT - 1) / T3D_UNIT;
-    const int per_shard = (n_units + T3D_SHARDS - 1) / T3D_SHARDS;   // places in a shard's list (the last ones may lie beyond the band)
-    const float amb_k = 2.0f / 255.0f;  // absent children count as ambient * 2/255 (T3DR.py:1054-1055)
-    // LDS and global memory written by this wave and read by this wave later: the hardware keeps one wave's accesses to an
-    // address in order, the fences only stop the compiler from moving a read above the write it depends on
-    auto lds_sync = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    };
-    lds_sync();
-    int q_head = 0, q_tail = 0;            // ring positions (taken modulo q_cap); all wave-uniform
-    int list_head = 0, list_tail = 0;      // waiting camera rays (positions taken modulo T3D_PRIM_LIST)
-    int ring_nodes = 0, items_done = 0;    // nodes that entered the LDS ring; (node, light) pairs traced
-    bool units_left = true;
-
-    // ---- colours of a finished unit: its nodes, deepest level first (k_resolve for this wave's own nodes) ----
-    auto resolve_slot = [&](int s) {
-        const int base_node = s << slot_shift;
-        const int n_nodes = min(s_nn[s], slot_cap);
-        for (int lv = rp.bounces; lv >= 0; --lv) {
-            int lv_nodes = 0, lv_spawned = 0;
-            for (int base = 0; base < n_nodes; base += 64) {
-                const int k = base_node + base + lane;
-                const bool in_range = base + lane < n_nodes;
-                float4 d4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                int meta = -1;
-                if (in_range) { d4 = nd[k]; meta = __float_as_int(d4.w); }
-                const bool mine = in_range && ((meta >> 24) & 15) == lv;
-                const unsigned long long mm = __ballot(mine);
-                if (mm == 0ull) continue;   // wave-uniform: nodes are stored nearly breadth first, a block of 64 holds few levels
-                lv_nodes += __popcll(mm);
-                if (mine) {
-                    const float4 c4 = nc[k];
-                    const int shader = meta & ((1 << T3D_META_SHADER_BITS) - 1), side = (meta >> 30) & 1;
-                    const int parent = nparent[k];
-                    const DevShader sh = sc.shaders[shader];
-                    float I = 0.0f;
-                    for (int l = 0; l < L; ++l) I += nli[(size_t)k * L + l];  // light order, T3DR.py:894
-                    float res[3];
-                    node_color(sc, rp, sh, c4, d4, I, res);
-                    if (lv == 0) {
-                        if (out.bgr) store_pixel(out.bgr, out.radiance, parent, res[0], res[1], res[2], 1.0f);
-                        else out.sample_color[parent] = make_float4(res[0], res[1], res[2], 0.0f);
-                    } else {
-                        const float att = c4.w;
-                        float4* slot = side ? nd : nc;
-                        *(float3*)&slot[parent] = make_float3(res[0] * att, res[1] * att, res[2] * att);
-                    }
-                }
-                int sp = mine ? (meta >> T3D_META_SHADER_BITS) & 3 : 0;
-                for (int off = 32; off > 0; off >>= 1) sp += __shfl_xor(sp, off);
-                lv_spawned += sp;
-            }
-            if (lane == 0) { stat[T3D_STATS_MAX_LEVELS + lv] += lv_nodes; if (lv + 1 < T3D_STATS_MAX_LEVELS) stat[lv + 1] += lv_spawned; }
-            lds_sync();   // the slots this level wrote are read by the next one
-        }
-    };
-
-    // ---- everything after the closest hit of one ray per lane: leaves, node records, child rays, ring entries.
-    //      primary: this lane's ray is a camera ray; my_slot: the node region of this lane's unit ----
-    auto finish = [&](const RayIn& r, const Hit& hk, bool primary, int my_slot) {
-        const int level = 31 - __clz((int)(r.heap & 0xFFFFu));
-        const Outcome oc = hit_outcome(sc, spheres, rp, r, hk, primary, level < rp.bounces, out);
-        if (r.active && (!oc.hit || oc.emitter)) {
-            if (primary) {
-                const V3 cl = oc.hit ? oc.emit : mk(rp.ambient[0], rp.ambient[1], rp.ambient[2]);  // T3DR.py:1006-1007
-                if (out.bgr) store_pixel(out.bgr, out.radiance, r.i, cl.x, cl.y, cl.z, 1.0f);
-                else out.sample_color[r.i] = make_float4(cl.x, cl.y, cl.z, 0.0f);
-            } else if (oc.hit) {
-                float4* slot = r.side ? nd : nc;
-                *(float3*)&slot[r.parent] = make_float3(oc.emit.x * oc.att_parent, oc.emit.y * oc.att_parent, oc.emit.z * oc.att_parent);
-            }
-        }
-        // a node's place in its unit's region: one LDS atomic per shaded lane.  A node that does not fit is not stored and
-        // has no children, a ring without room takes no rays at all (wave-uniform): nothing in the ring is ever unwritten.
-        // Either way the frame is invalid and is traced again with more room (the overflow flag).
-        int node = 0;
-        bool stored = false;
-        if (oc.shaded) {
-            const int idx = atomicAdd(&s_nn[my_slot], 1);
-            stored = idx < slot_cap;
-            node = (my_slot << slot_shift) + (stored ? idx : 0);
-        }
-        bool want_t = oc.want_t && stored, want_b = oc.want_b && stored;
-        const unsigned long long m_n = __ballot(oc.shaded);
-        unsigned long long m_t = __ballot(want_t), m_b = __ballot(want_b);
-        const bool room = (q_tail + __popcll(m_t) + __popcll(m_b)) - q_head <= wp.q_cap;
-        if (!room) { want_t = false; want_b = false; m_t = 0ull; m_b = 0ull; }
-        if ((oc.shaded && !stored) || (!room && lane == 0)) { cnt->overflow = 1; rp.sticky[0] = 1; }
-        const int c_n = __popcll(m_n), c_t = __popcll(m_t), c_b = __popcll(m_b);
-        // the unit's books: this ray is done, its children wait; the unit's latest node
-        if (r.active) {
-            const int delta = (int)want_t + (int)want_b - 1;
-            if (delta != 0) atomicAdd(&s_live[my_slot], delta);
-            if (oc.shaded) s_ring_end[my_slot] = ring_nodes + c_n;
-        }
-        const int nrank = __popcll(m_n & lt_mask);
-        const int tpos = q_tail + __popcll(m_t & lt_mask), bpos = q_tail + c_t + __popcll(m_b & lt_mask);
-        if (stored) {
-            const int spawned = (int)want_t + (int)want_b;
-            nc[node] = make_float4(rp.ambient[0] * amb_k, rp.ambient[1] * amb_k, rp.ambient[2] * amb_k, oc.att_parent);
-            nd[node] = make_float4(rp.ambient[0] * amb_k, rp.ambient[1] * amb_k, rp.ambient[2] * amb_k,
-                                   __int_as_float(oc.shader | (spawned << T3D_META_SHADER_BITS) | (level << 24) | (r.side << 30)));
-            nparent[node] = primary ? r.i : r.parent;
-        }
-        if (want_t) {
-            RayRec rec;
-            rec.o = make_float4(oc.tstart.x, oc.tstart.y, oc.tstart.z, oc.t_ior);
-            rec.d = make_float4(oc.tdir.x, oc.tdir.y, oc.tdir.z, __int_as_float(oc.t_obj));
-            rec.p = make_float4(r.o.x, r.o.y, r.o.z, __int_as_float(node));
-            rec.k = make_uint4(0u, oc.child_heap + 1u, 1u, r.pixel_hash);
-            q[tpos & q_mask] = rec;
-        }
-        if (want_b) {
-            RayRec rec;
-            rec.o = make_float4(oc.bstart.x, oc.bstart.y, oc.bstart.z, r.ior);
-            rec.d = make_float4(oc.bdir.x, oc.bdir.y, oc.bdir.z, __int_as_float(r.inside_obj));
-            rec.p = make_float4(r.o.x, r.o.y, r.o.z, __int_as_float(node));
-            rec.k = make_uint4(0u, oc.child_heap, 0u, r.pixel_hash);
-            q[bpos & q_mask] = rec;
-        }
-        if (oc.shaded && L > 0) {   // shaded nodes enter the wave's ring in lane order
-            const int slot = (ring_nodes + nrank) % RING;
-            ring_a[slot] = make_float4(oc.P.x, oc.P.y, oc.P.z, oc.rough);
-            ring_b[slot] = make_float4(oc.N.x, oc.N.y, oc.N.z, __int_as_float(node));
-        }
-        ring_nodes += c_n;
-        q_tail += c_t + c_b;
-    };
-
-    int idle = 0;   // turns of the loop below that did no round: bounded, whatever state the books are in
-    const unsigned long long t_start = wall_clock64();
-    unsigned long long t_dry = 0;   // when the shard had no unit left for this wave
-    for (;;) {
-        lds_sync();
-        // ---- units whose last ray and last shadow ray are done: colours, pixels, region free again ----
-        {
-            const bool done = lane < T3D_SLOTS && s_busy[lane] != 0 && s_live[lane] == 0 && (long long)items_done >= (long long)s_ring_end[lane] * L;
-            const unsigned long long fin0 = __ballot(done);
-            for (unsigned long long fin = fin0; fin != 0ull; fin &= fin - 1ull) {
-                const int s = (int)__builtin_ctzll(fin);
-                resolve_slot(s);
-                if (lane == 0) { s_busy[s] = 0; s_nn[s] = 0; s_ring_end[s] = 0; }
-            }
-            if (fin0 != 0ull) lds_sync();
-        }
-        if (ring_nodes * L == items_done && ring_nodes > 0) {
-            // nothing pending: the two counters start again from zero (they would otherwise grow with the band)
-            ring_nodes = 0; items_done = 0;
-            if (lane < T3D_SLOTS) s_ring_end[lane] = 0;
-            lds_sync();
-        }
-        const int pending = ring_nodes * L - items_done;
-        const int queued = q_tail - q_head;
-        bool shadow_now = pending >= 128;
-        if (!shadow_now) {
-            // ---- camera rays for the lanes the ring cannot fill: take units until enough of their rays are waiting ----
-            while (units_left && queued + (list_tail - list_head) < 128) {
-                unsigned long long fr = __ballot(lane < T3D_SLOTS && s_busy[lane] == 0);
-                if (fr == 0ull) break;                 // every region is in use: go on with what there is
-                // up to four units at a time, 16 lanes each: as many as there are lanes to fill and regions free
-                const int missing = 128 - queued - (list_tail - list_head);
-                int n_take = (missing + T3D_UNIT - 1) / T3D_UNIT;
-                n_take = min(min(n_take, 4), __popcll(fr));
-                // units of shard s are s, s + 64, s + 128, ..., handed out by the shard's counter (64 counters, each in a line of its
-                // own: even the first round of requests, one per wave, is 64 atomics deep per counter)
-                int j = 0;
-                if (lane == 0) j = atomicAdd(&cnt->unit_next[shard].v, n_take);
-                j = __builtin_amdgcn_readfirstlane(j);
-                if (j >= per_shard) { units_left = false; t_dry = wall_clock64(); break; }
-                // one camera ray per lane; those that miss the scene's bounding box hit nothing: ambient, at once (T3DR.py:1006-1007)
-                const int sub = lane >> 4;
-                const long long jj = j + sub < per_shard ? ((long long)(j + sub) * rp.unit_stride) % per_shard : (long long)per_shard;
-                const long long u = jj * T3D_SHARDS + shard;
-                RayIn t;
-                load_ray<true>(sc, rp, nullptr, (int)(u * T3D_UNIT) + (lane & 15), sub < n_take && u < n_units ? rp.n0 : 0, 0, t);
-                const bool meets = t.active && ray_meets_scene_box(sc.geo, t.o, t.d);
-                if (t.active && !meets) {
-                    if (out.bgr) store_pixel(out.bgr, out.radiance, t.i, rp.ambient[0], rp.ambient[1], rp.ambient[2], 1.0f);
-                    else out.sample_color[t.i] = make_float4(rp.ambient[0], rp.ambient[1], rp.ambient[2], 0.0f);
-                    if (t.smp == 0) {
-                        const int pix = t.i / rp.samples;
-                        if (out.primary) { out.primary[2 * pix] = -1; out.primary[2 * pix + 1] = -1; }
-                        if (out.primary_t) out.primary_t[pix] = __builtin_nanf("");
-                    }
-                }
-                const unsigned long long mk_ = __ballot(meets);
-                if (mk_ == 0ull) continue;             // nothing of these units needs tracing
-                int my_s = 0;
-                for (int i = 0; i < n_take; ++i) {     // a region for every unit that has rays to trace
-                    const int n_i = __popcll(mk_ & (0xFFFFull << (16 * i)));
-                    if (n_i == 0) continue;
-                    const int si = (int)__builtin_ctzll(fr);
-                    fr &= fr - 1ull;
-                    if (sub == i) my_s = si;
-                    if (lane == 0) { s_busy[si] = 1; s_live[si] = n_i; s_nn[si] = 0; s_ring_end[si] = 0; }
-                }
-                if (meets) prim_list[(list_tail + __popcll(mk_ & lt_mask)) % T3D_PRIM_LIST] = ((int)(u * T3D_UNIT) + (lane & 15)) | (my_s << 26);
-                list_tail += __popcll(mk_);
-                lds_sync();
-            }
-            if (queued + (list_tail - list_head) == 0) {
-                if (pending > 0) {
-                    shadow_now = true;     // the last, part-filled shadow round of what this wave has
-                } else {
-                    // nothing to trace and nothing pending: units that have just become complete are resolved by the next turn; a
-                    // wave whose books claim otherwise (cannot happen) must not spin
-                    const unsigned long long busy = __ballot(lane < T3D_SLOTS && s_busy[lane] != 0);
-                    if ((busy != 0ull || units_left) && ++idle < 4) continue;
-                    if (busy != 0ull || units_left) { if (lane == 0) { cnt->overflow = 1; rp.sticky[0] = 1; } }
-                    break;
-                }
-            }
-        }
-        idle = 0;
-        if (shadow_now) {
-            // ---------------- shadow round (see k_level) ----------------
-            const int take = pending < 128 ? pending : 128;
-            const int item0 = items_done + lane, item1 = item0 + 64;
-            const bool run0 = item0 < ring_nodes * L, run1 = item1 < ring_nodes * L;
-            const int nd_base = __builtin_amdgcn_readfirstlane(items_done / L), l_base = __builtin_amdgcn_readfirstlane(items_done % L);
-            const int x0 = l_base + (run0 ? lane : 0), x1 = l_base + (run1 ? lane + 64 : 0);
-            const int q0 = (int)(((float)x0 + 0.5f) * inv_L), q1 = (int)(((float)x1 + 0.5f) * inv_L);
-            const int nd0 = nd_base + q0, nd1 = nd_base + q1;
-            const int l0 = x0 - q0 * L, l1 = x1 - q1 * L;
-            const float4 rb0 = ring_b[nd0 % RING], rb1 = ring_b[nd1 % RING];
-            const ShadowRay s0 = shadow_ray(sc, ring_a[nd0 % RING], rb0, l0);
-            const ShadowRay s1 = shadow_ray(sc, ring_a[nd1 % RING], rb1, l1);
-            Hit h0, h1;
-            closest_hit2<false, true>(GEO_ARGS, sc.geo, s0.start, s0.Ld, s1.start, s1.Ld, true, false, false, h0, h1);
-            const float I0 = shadow_intensity(sc, spheres, s0, h0), I1 = shadow_intensity(sc, spheres, s1, h1);
-            if (run0) nli[(size_t)__float_as_int(rb0.w) * L + l0] = I0;
-            if (run1) nli[(size_t)__float_as_int(rb1.w) * L + l1] = I1;
-            if (lane == 0) { stat[2 * T3D_STATS_MAX_LEVELS + 2] += 1; stat[2 * T3D_STATS_MAX_LEVELS + 3] += take; }
-            items_done += take;
-            continue;
-        }
-        const int listed = list_tail - list_head;
-        // ---------------- trace round: lanes 0 .. n_q - 1 take rays from the head of the ring, the next n_p lanes camera rays ----------------
-        // Only origin, direction and medium of the two rays of a lane are held through the closest-hit loop; what the
-        // classification needs besides (parent, keys of the random numbers, ...) is fetched again afterwards, ray by
-        // ray, from the ring (an L1 hit) or from the sample number: registers for waves, not for baggage.
-        const int n_q = queued < 128 ? queued : 128;
-        const int n_p = listed < 128 - n_q ? listed : 128 - n_q;
-        auto aim = [&](int k, V3& o, V3& d, bool& cull, bool& see) {
-            o = mk(0, 0, 0); d = mk(0, 0, 1); cull = true; see = true;
-            const int slot_in_round = 64 * k + lane;
-            if (slot_in_round < n_q) {
-                const RayRec* rec = &q[(q_head + slot_in_round) & q_mask];
-                const float4 o4 = rec->o;
-                const float4 d4 = rec->d;
-                o = mk(o4.x, o4.y, o4.z); d = mk(d4.x, d4.y, d4.z); cull = o4.w == 1.0f;
-            } else if (slot_in_round < n_q + n_p) {
-                const int e = prim_list[(list_head + slot_in_round - n_q) % T3D_PRIM_LIST];
-                RayIn t;
-                load_ray<true>(sc, rp, nullptr, e & (T3D_FRAME_MAX_SAMPLES - 1), rp.n0, 0, t);
-                o = t.o; d = t.d; cull = t.ior == 1.0f; see = rp.lights != 0;
-            }
-        };
-        V3 ro0, rd0, ro1, rd1;
-        bool cull0, cull1, see0, see1;
-        aim(0, ro0, rd0, cull0, see0);
-        aim(1, ro1, rd1, cull1, see1);
-        Hit h0, h1;  // back faces culled iff ray.ior == 1 (T3DR.py:961); only primary rays may be blind to Light objects
-        closest_hit2<false>(GEO_ARGS, sc.geo, ro0, rd0, ro1, rd1, true, cull0, cull1, h0, h1, see0, see1);
-        auto again = [&](int k, RayIn& r, bool& primary, int& my_slot) {
-            int slot_in_round = 64 * k + lane;
-            asm volatile("" : "+v"(slot_in_round));   // a second look at the same ray, not a value to keep alive across the loop above
-            primary = false; my_slot = 0;
-            r.active = false;
-            r.i = 0;
-            r.o = mk(0, 0, 0); r.d = mk(0, 0, 1); r.pstart = mk(0, 0, 0);
-            r.ior = 1.0f; r.inside_obj = -1; r.parent = 0; r.side = 0;
-            r.ps = 0; r.heap = 1; r.pixel_hash = 0; r.px = 0; r.py = 0; r.smp = 0;
-            if (slot_in_round < n_q) {
-                const RayRec rec = q[(q_head + slot_in_round) & q_mask];
-                r.active = true;
-                r.o = mk(rec.o.x, rec.o.y, rec.o.z); r.ior = rec.o.w;
-                r.d = mk(rec.d.x, rec.d.y, rec.d.z); r.inside_obj = __float_as_int(rec.d.w);
-                r.pstart = mk(rec.p.x, rec.p.y, rec.p.z); r.parent = __float_as_int(rec.p.w);
-                r.heap = rec.k.y; r.side = (int)rec.k.z; r.pixel_hash = rec.k.w;
-                my_slot = (r.parent >> slot_shift) & (T3D_SLOTS - 1);
-            } else if (slot_in_round < n_q + n_p) {
-                const int e = prim_list[(list_head + slot_in_round - n_q) % T3D_PRIM_LIST];
-                load_ray<true>(sc, rp, nullptr, e & (T3D_FRAME_MAX_SAMPLES - 1), rp.n0, 0, r);
-                primary = true;
-                my_slot = (e >> 26) & (T3D_SLOTS - 1);
-            }
-        };
-        {
-            RayIn r; bool primary; int my_slot;
-            again(0, r, primary, my_slot);
-            finish(r, h0, primary, my_slot);
-        }
-        {
-            RayIn r; bool primary; int my_slot;
-            again(1, r, primary, my_slot);
-            finish(r, h1, primary, my_slot);
-        }
-        if (lane == 0) { stat[2 * T3D_STATS_MAX_LEVELS] += 1; stat[2 * T3D_STATS_MAX_LEVELS + 1] += n_q + n_p; }
-        // (the ring's head moves on only after the round: until then the entries of this round are looked at again)
-        q_head += n_q;
-        list_head += n_p;
-        if (list_head >= T3D_PRIM_LIST) { list_head -= T3D_PRIM_LIST; list_tail -= T3D_PRIM_LIST; }
-    }
-    // statistics: rays and nodes per level, one atomic each per wave, on the wave's own counter lines
-    lds_sync();
-    if (lane <= rp.bounces) {
-        if (lane > 0 && stat[lane]) atomicAdd(&cnt->n_rays[lane][shard].v, stat[lane]);
-        if (stat[T3D_STATS_MAX_LEVELS + lane]) atomicAdd(&cnt->n_nodes[lane][shard].v, stat[T3D_STATS_MAX_LEVELS + lane]);
-    }
-    // how full the rounds were (trace rounds, rays in them, shadow rounds, pairs in them): next to the traversal counters, which this path leaves unused
-    if (lane < 4) atomicAdd(&cnt->bvh_stat[shard][4 + lane], (unsigned long long)stat[2 * T3D_STATS_MAX_LEVELS + lane]);
-    if (lane == 0) atomicMax(&cnt->bvh_stat[shard][3], (unsigned long long)(stat[2 * T3D_STATS_MAX_LEVELS] + stat[2 * T3D_STATS_MAX_LEVELS + 2]));   // the busiest wave's rounds
-    if (lane == 0) {   // wave lifetimes (100 MHz ticks): sum, longest, and the sum of the parts after the units ran out
-        const unsigned long long t_end = wall_clock64();
-        atomicMax(&cnt->frame_dbg[0], ~t_start);   // earliest start, as the maximum of the complement (the field starts at zero)
-        atomicMax(&cnt->frame_dbg[1], t_start);    // latest start
-        atomicMax(&cnt->frame_dbg[2], t_end);      // latest end
-        atomicAdd(&cnt->bvh_stat[shard][0], t_end - t_start);
-        atomicMax(&cnt->bvh_stat[shard][1], t_end - t_start);
-        atomicAdd(&cnt->bvh_stat[shard][2], t_dry ? t_end - t_dry : 0ull);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // LBVH path: one tree level = three launches.
 //   k_bvh_trace    closest hit of every ray of the level -> hits[]
 //   k_bvh_process  classification, child rays, node records (process_ray) from the stored hits; the shading
@@ -1775,9 +1371,6 @@ struct Work {
     float4* src_a[2] = {nullptr, nullptr}; float4* src_b[2] = {nullptr, nullptr};  // by level parity: see render_band
     size_t n0 = 0;       // primary samples sample_color holds
     float4* sample_color = nullptr;
-    // k_frame (one launch per band, scenes traced by brute force): wave-private rings and node arrays
-    WavePool wp{};
-    size_t wp_waves = 0; int wp_lights = 0;
     uint64_t gen = 0;    // counts (re)allocations: a launch graph holds the addresses
 };
 
@@ -1818,8 +1411,6 @@ struct t3d_ctx {
     bool timing = true;       // record an event after every k_level launch (t3d_set_timing)
     bool last_timed = true;
     bool last_events = true;   // the band recorded its start and end
-    int last_trace_launches = 0;
-    int last_frame_waves = 1;
     bool last_valid = false; int last_levels = 0; size_t last_n0 = 0; int last_lights = 1; uint64_t last_launches = 0;
     hipStream_t last_stream = nullptr;
     // Launch graphs of repeated asynchronous bands: the same band (same options, rows, buffers, scene) asked for again
@@ -1831,7 +1422,6 @@ struct t3d_ctx {
     int graph_miss_next = 0;
     bool graphs_enabled = true;
     bool full_rounds = false;       // t3d_set_rounds
-    bool frame_kernel = true;       // brute-force scenes: one k_frame launch per band instead of a launch per tree level
     uint64_t scene_gen = 0;         // counts uploads
     // Overflow that nobody was waiting for.  An asynchronous render call (no stats) returns before its kernels have run, so
     // a trace tree that outgrows the queues or node arrays cannot be reported by that call.  The kernels raise these two
@@ -1842,10 +1432,8 @@ struct t3d_ctx {
     int* h_sticky = nullptr;
     size_t async_min_cap = 0;       // entries per level that asynchronous calls start with: twice what the last one that overflowed had
     size_t last_async_cap = 0;      // entries per level of the most recent asynchronous band
-    int last_async_kind = 0;        // ... which was: 0 a band of per-level launches, 1 a band of t3d_render_rows_device_static, 2 a k_frame launch
+    bool last_async_static = false; // ... which was a band of t3d_render_rows_device_static
     int static_async_factor = 2;    // rays per sample and level that asynchronous static calls provide for: doubled after an overflow
-    int frame_factor = 8;           // k_frame launches: room per primary sample that calls start with; what a checked call had to
-                                    // grow to, or an asynchronous one was found to lack, later calls start from
     // cancellation (Photon.render's cancelCallback, T3DR.py:1227-1237)
     int (*cancel_cb)(void*) = nullptr; void* cancel_user = nullptr;
     // t3d_closest_hits: pinned staging the kernel reads its rays from and writes its answers to
@@ -1898,7 +1486,6 @@ extern "C" int t3d_create(int device, t3d_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_sm = prop.multiProcessorCount;
     if (getenv("T3D_NO_GRAPHS")) c->graphs_enabled = false;
-    if (getenv("T3D_PER_LEVEL")) c->frame_kernel = false;   // the launch-per-level path, for comparisons
     // working-set budget of one band in MiB (default 48 GiB): small values make small frames take the paths of huge ones
     if (const char* mb = getenv("T3D_MEM_BUDGET_MB")) { const long v = atol(mb); if (v > 0) c->mem_budget = (size_t)v << 20; }
     if (hipMalloc((void**)&c->d_cnt_pair[0], sizeof(Counters)) != hipSuccess || hipMalloc((void**)&c->d_cnt_pair[1], sizeof(Counters)) != hipSuccess ||
@@ -1930,7 +1517,6 @@ static void free_work(Work& w) {
     hipFree(w.hits);
     for (int k = 0; k < 2; ++k) { hipFree(w.src_a[k]); hipFree(w.src_b[k]); }
     hipFree(w.sample_color);
-    hipFree(w.wp.q); hipFree(w.wp.c); hipFree(w.wp.d); hipFree(w.wp.parent); hipFree(w.wp.li);
     w = Work{};
     w.gen = gen;
 }
@@ -2275,30 +1861,6 @@ static int ensure_work(t3d_ctx* c, Work& w, size_t cap, int levels, size_t n0, b
     return T3D_OK;
 }
 
-// Wave-private work memory of k_frame: `waves` rings of q_cap rays and T3D_SLOTS node regions of 1 << slot_shift nodes.
-static int ensure_wave_work(t3d_ctx* c, Work& w, size_t waves, int q_cap, int slot_shift, size_t n0) {
-    const int L = c->sc.n_lights > 0 ? c->sc.n_lights : 1;
-    if (waves > w.wp_waves || q_cap > w.wp.q_cap || slot_shift > w.wp.slot_shift || L > w.wp_lights) {
-        hipFree(w.wp.q); hipFree(w.wp.c); hipFree(w.wp.d); hipFree(w.wp.parent); hipFree(w.wp.li);
-        w.wp = WavePool{}; w.wp_waves = 0; w.wp_lights = 0;
-        w.gen++;
-        const size_t n_cap = (size_t)T3D_SLOTS << slot_shift;
-        HIPCHK(c, hipMalloc((void**)&w.wp.q, sizeof(RayRec) * waves * (size_t)q_cap));
-        HIPCHK(c, hipMalloc((void**)&w.wp.c, sizeof(float4) * waves * n_cap));
-        HIPCHK(c, hipMalloc((void**)&w.wp.d, sizeof(float4) * waves * n_cap));
-        HIPCHK(c, hipMalloc((void**)&w.wp.parent, sizeof(int) * waves * n_cap));
-        HIPCHK(c, hipMalloc((void**)&w.wp.li, sizeof(float) * waves * n_cap * (size_t)L));
-        w.wp.q_cap = q_cap; w.wp.n_cap = (int)n_cap; w.wp.slot_shift = slot_shift; w.wp_waves = waves; w.wp_lights = L;
-    }
-    if (n0 > w.n0) {
-        hipFree(w.sample_color); w.sample_color = nullptr; w.n0 = 0;
-        w.gen++;
-        HIPCHK(c, hipMalloc((void**)&w.sample_color, sizeof(float4) * n0));
-        w.n0 = n0;
-    }
-    return T3D_OK;
-}
-
 static int check_opts(t3d_ctx* c, const t3d_opts* o, int row0, int nrows) {
     if (!c) return T3D_E_INVALID;
     if (!c->has_scene) { c->err = "no scene uploaded"; return T3D_E_INVALID; }
@@ -2359,29 +1921,10 @@ static void fill_stats(t3d_ctx* c, t3d_stats* stats) {
         stats->tri_tests += q * (uint64_t)c->sc.n_tris;
         stats->sphere_tests += q * (uint64_t)c->sc.n_spheres - (c->last_lights ? 0 : c->last_n0 * (uint64_t)c->n_light_objs);
     }
-    if (getenv("T3D_FRAME_STATS") && !c->use_bvh) {
-        unsigned long long r[4] = {0, 0, 0, 0};
-        for (int sh = 0; sh < T3D_SHARDS; ++sh) for (int k = 0; k < 4; ++k) r[k] += c->h_cnt->bvh_stat[sh][4 + k];
-        unsigned long long busiest = 0, life = 0, longest = 0, dry = 0;
-        for (int sh = 0; sh < T3D_SHARDS; ++sh) {
-            busiest = c->h_cnt->bvh_stat[sh][3] > busiest ? c->h_cnt->bvh_stat[sh][3] : busiest;
-            life += c->h_cnt->bvh_stat[sh][0]; dry += c->h_cnt->bvh_stat[sh][2];
-            longest = c->h_cnt->bvh_stat[sh][1] > longest ? c->h_cnt->bvh_stat[sh][1] : longest;
-        }
-        fprintf(stderr, "k_frame: wave lifetime mean %.1f us, longest %.1f us, mean time after the last unit was taken %.1f us (%d waves); "
-                "last wave started %.1f us after the first, kernel span %.1f us\n",
-                life / 100.0 / c->last_frame_waves, longest / 100.0, dry / 100.0 / c->last_frame_waves, c->last_frame_waves,
-                (c->h_cnt->frame_dbg[1] - ~c->h_cnt->frame_dbg[0]) / 100.0, (c->h_cnt->frame_dbg[2] - ~c->h_cnt->frame_dbg[0]) / 100.0);
-        if (r[0]) fprintf(stderr, "k_frame: %llu trace rounds %.1f%% full, %llu shadow rounds %.1f%% full; busiest wave %llu rounds\n", r[0], 100.0 * r[1] / (128.0 * r[0]), r[2],
-                          r[2] ? 100.0 * r[3] / (128.0 * r[2]) : 0.0, busiest);
-    }
     stats->nodes += nodes;  // shaded nodes only; emitter leaves are folded into their parents
     stats->launches += c->last_launches;
-    stats->n_k_level += (uint64_t)c->last_trace_launches;
+    stats->n_k_level += (uint64_t)levels;
 }
-
-// Scenes traced by brute force go through k_frame: one launch per band, work memory per resident wave.
-static bool frame_path(const t3d_ctx* c) { return c->frame_kernel && !c->use_bvh && c->sc.n_shaders < (1 << T3D_META_SHADER_BITS); }
 
 // Trace one band whose outputs are device pointers, with the work buffers `w` (grown as needed unless `fixed_work`:
 // then `w` has been laid out by the caller and must already hold `cap_factor` entries per primary sample).  Returns
@@ -2400,32 +1943,7 @@ static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int nro
     if (cap < min_cap && min_cap * (size_t)levels <= (size_t)0x7FFFFFF0) cap = min_cap;
     cap = (cap + shards * 64 - 1) / (shards * 64) * (shards * 64);
     if (cap * (size_t)levels > (size_t)0x7FFFFFF0) { c->err = "band too large for 32-bit node indices"; return T3D_E_CAPACITY; }
-    // Scenes traced by brute force: the whole band in one launch of wave-autonomous work (k_frame).  Its memory is per
-    // resident wave, not per pixel: a unit of `unit` primary samples at a time, a ring of q_cap rays, n_cap nodes.
-    const bool use_frame = frame_path(c) && !single && !fixed_work;
-    int frame_waves = 0, frame_unit = 0;
-    if (use_frame) {
-        const size_t resident = (size_t)c->n_sm * 16;   // 4 waves per SIMD at this kernel's register count
-        frame_unit = T3D_UNIT;
-        const size_t n_units = (n0 + frame_unit - 1) / frame_unit;
-        size_t waves = ((n_units + 3) / 4 + T3D_SHARDS - 1) / T3D_SHARDS * T3D_SHARDS;   // a wave's first four units are fixed
-        if (waves > resident) waves = resident;
-        // room: node regions of 2 * factor nodes per sample of a unit (a unit of samples that all see glass at 4 bounces wants
-        // about 15 nodes each; one that sees walls, 5) and a ring of 128 * factor rays
-        if (cap_factor > (1 << 20) / frame_unit) { c->err = "trace tree too large"; return T3D_E_CAPACITY; }
-        if (n0 > (size_t)T3D_FRAME_MAX_SAMPLES) { c->err = "band too large"; return T3D_E_CAPACITY; }
-        int q_cap = 1024, slot_shift = 8;
-        while (q_cap < 128 * cap_factor) q_cap *= 2;
-        while ((1 << slot_shift) < frame_unit * cap_factor * 2) ++slot_shift;
-        // many lights make a wave's node regions heavy (4 bytes per node and light): fewer waves then, within the budget
-        const size_t per_wave = sizeof(RayRec) * (size_t)q_cap + ((size_t)T3D_SLOTS << slot_shift) * (36 + 4 * (size_t)(c->sc.n_lights > 0 ? c->sc.n_lights : 1));
-        size_t fit = c->mem_budget / per_wave / T3D_SHARDS * T3D_SHARDS;
-        if (fit < T3D_SHARDS) fit = T3D_SHARDS;
-        if (waves > fit) waves = fit;
-        int rc = ensure_wave_work(c, w, waves, q_cap, slot_shift, n0);
-        if (rc) return rc;
-        frame_waves = (int)waves;
-    } else if (fixed_work) {
+    if (fixed_work) {
         if (cap > w.cap || levels > w.levels || n0 > w.n0) { c->err = "render_band: fixed work buffers too small"; return T3D_E_CAPACITY; }
     } else {
         int rc = ensure_work(c, w, cap, levels, n0, single != nullptr);
@@ -2437,17 +1955,7 @@ static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int nro
     rp.row_stride = o->row_stride > 1 ? o->row_stride : 1;
     rp.bounces = o->bounces; rp.samples = single ? 1 : S; rp.lights = o->lights; rp.seed = o->seed;
     for (int k = 0; k < 3; ++k) rp.ambient[k] = (float)o->ambient[k];
-    rp.cap = (int)(fixed_work || use_frame ? cap : w.cap);
-    rp.unit = frame_unit;
-    if (use_frame) {
-        // a stride near 0.618 of the list's length that shares no factor with it: (n * stride) mod length visits every place once
-        const long long per_shard = (long long)((n0 + T3D_UNIT - 1) / T3D_UNIT + T3D_SHARDS - 1) / T3D_SHARDS;
-        auto gcd = [](long long a, long long b) { while (b) { const long long t = a % b; a = b; b = t; } return a; };
-        long long stride = (long long)(0.6180339887 * (double)per_shard);
-        if (stride < 1) stride = 1;
-        while (gcd(stride, per_shard) != 1) ++stride;
-        rp.unit_stride = (int)(stride % per_shard == 0 ? 1 : stride);
-    }
+    rp.cap = (int)(fixed_work ? cap : w.cap);
     rp.n0 = (int)n0;
     rp.resident_waves = c->n_sm * 16;   // 4 waves per SIMD at this kernel's register count
     rp.tiled = !single && o->width % 16 == 0 && nrows % 8 == 0;
@@ -2513,9 +2021,8 @@ static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int nro
     if (graphable) {
         memset(key, 0, sizeof key);
         memcpy(key, &rp, sizeof rp);
-        const void* ptrs[12] = {d_bgr, d_rad, d_prim, d_prim_t, c->d_cnt, next_cnt, use_frame ? (void*)w.wp.q : (void*)w.rays[0], w.rays[1],
-                                use_frame ? w.wp.c : w.pool.c, use_frame ? w.wp.li : w.pool.li,
-                                w.sample_color, (const void*)(uintptr_t)((c->scene_gen << 32) ^ w.gen ^ ((uint64_t)frame_waves << 48))};
+        const void* ptrs[12] = {d_bgr, d_rad, d_prim, d_prim_t, c->d_cnt, next_cnt, w.rays[0], w.rays[1], w.pool.c, w.pool.li,
+                                w.sample_color, (const void*)(uintptr_t)((c->scene_gen << 32) ^ w.gen)};
         memcpy(key + sizeof rp, ptrs, sizeof ptrs);
         for (auto& g : c->graphs)
             if (g.valid && memcmp(g.key, key, sizeof key) == 0) {
@@ -2532,18 +2039,7 @@ static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int nro
         }
     }
     if (events) HIPCHK(c, tick());  // ev[0]: start of the call
-    if (use_frame) {
-        WavePool wp = w.wp;   // the arrays may be larger than this band needs: what the kernel indexes with is what was allocated
-        hipLaunchKernelGGL(k_frame, dim3(frame_waves / T3D_WAVES), dim3(T3D_BLOCK), 0, st, c->sc, planes, pfirst, uv, sph, rp, wp, c->d_cnt, out,
-                           (uint4*)next_cnt, (int)(sizeof(Counters) / sizeof(uint4)));
-        launches += 1;
-        if (c->timing) for (int d = 0; d < levels; ++d) HIPCHK(c, tick());   // one launch traces every level: its time is booked on level 0
-        if (cancellable) {
-            HIPCHK(c, hipStreamSynchronize(st));
-            if (c->cancel_cb(c->cancel_user)) cancelled = true;
-        }
-    }
-    for (int d = 0; d < levels && !use_frame; ++d) {
+    for (int d = 0; d < levels; ++d) {
         RayRec* in = w.rays[d & 1];
         RayRec* outq = w.rays[(d + 1) & 1];
         const int grid_n = single ? 1 : trace_blocks_for(d == 0 ? n0 : cap_used);
@@ -2602,7 +2098,7 @@ static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int nro
     }
     if (overlap && c->sc.n_lights > 0)   // the resolve reads every level's light intensities
         for (int d = levels >= 2 ? levels - 2 : 0; d < levels; ++d) HIPCHK(c, hipStreamWaitEvent(st, c->ev_shadowed[d], 0));
-    for (int d = levels - 1; d >= 0 && !use_frame; --d) {
+    for (int d = levels - 1; d >= 0; --d) {
         hipLaunchKernelGGL(k_resolve, dim3(single ? 1 : trace_blocks_for(cap_used)), dim3(T3D_BLOCK), 0, st, c->sc, rp, d, w.pool, c->d_cnt,
                            w.sample_color, d_dbg, dbg_cap, out.bgr, out.radiance, (uint4*)next_cnt, (int)(sizeof(Counters) / sizeof(uint4)));
         launches++;
@@ -2640,11 +2136,9 @@ issued:
     if (c->counters_on_host) HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
     c->last_timed = c->timing;
     c->last_events = events;
-    c->last_trace_launches = use_frame ? 1 : levels;
-    c->last_frame_waves = use_frame ? frame_waves : 1;
     c->last_levels = levels; c->last_n0 = n0; c->last_lights = o->lights; c->last_launches = launches; c->last_stream = st;
     c->last_valid = true;
-    if (!stats && !single) { c->last_async_cap = cap_used; c->last_async_kind = use_frame ? 2 : (fixed_work ? 1 : 0); return T3D_OK; }  // asynchronous use: an overflow raises the context's sticky words, see t3d_ctx
+    if (!stats && !single) { c->last_async_cap = cap_used; c->last_async_static = fixed_work; return T3D_OK; }  // asynchronous use: an overflow raises the context's sticky words, see t3d_ctx
     HIPCHK(c, hipStreamSynchronize(st));
     if (c->h_cnt->overflow) { c->h_sticky[0] = 0; return T3D_E_CAPACITY; }   // seen and dealt with by the caller: not left standing
     if (c->h_cnt->bvh_stack_overflow) { c->h_sticky[1] = 0; c->err = "LBVH traversal stack overflow"; return T3D_E_DEVICE; }
@@ -2661,8 +2155,7 @@ static int take_sticky(t3d_ctx* c) {
     }
     if (c->h_sticky[0]) {
         c->h_sticky[0] = 0;
-        if (c->last_async_kind == 1) { if (c->static_async_factor < (1 << T3D_MAX_BOUNCES)) c->static_async_factor *= 2; }
-        else if (c->last_async_kind == 2) { if (c->frame_factor < (1 << T3D_MAX_BOUNCES)) c->frame_factor *= 2; }
+        if (c->last_async_static) { if (c->static_async_factor < (1 << T3D_MAX_BOUNCES)) c->static_async_factor *= 2; }
         else c->async_min_cap = 2 * (c->last_async_cap > c->async_min_cap ? c->last_async_cap : c->async_min_cap);
         c->err = "an earlier asynchronous render call overflowed its node buffers (its output is invalid); asynchronous calls use larger buffers from now on";
         return T3D_E_CAPACITY;
@@ -2687,15 +2180,7 @@ extern "C" int t3d_render_rows_device(t3d_ctx* c, const t3d_opts* o, int row0, i
                                            (size_t)levels * (36 + 4 * (size_t)(c->sc.n_lights > 0 ? c->sc.n_lights : 1))) + sizeof(float4);
     size_t max_samples = c->mem_budget / per_sample;
     size_t max_idx = (size_t)0x7FFFFFF0 / ((size_t)levels * 2);
-    if (frame_path(c)) {
-        // k_frame's work memory does not grow with the band: what limits a band is 32-bit sample numbers and, with
-        // several samples per pixel, the 16 bytes of colour per sample
-        max_samples = S > 1 ? c->mem_budget / sizeof(float4) : (size_t)T3D_FRAME_MAX_SAMPLES;
-        max_idx = (size_t)T3D_FRAME_MAX_SAMPLES;
-    }
     if (max_samples > max_idx) max_samples = max_idx;
-    // somebody may want to stop this render: no band much longer than a millisecond
-    if (c->cancel_cb && frame_path(c) && max_samples > ((size_t)1 << 20)) max_samples = (size_t)1 << 20;
     int band = (int)(max_samples / ((size_t)o->width * S));
     if (band < 1) band = 1;
     if (band > nrows) band = nrows;
@@ -2707,7 +2192,7 @@ extern "C" int t3d_render_rows_device(t3d_ctx* c, const t3d_opts* o, int row0, i
         int nb = band < nrows - r ? band : nrows - r;
         size_t off = (size_t)r * o->width;
         // a call without stats cannot see an overflow and try again: it starts from what earlier overflows have taught
-        int factor = frame_path(c) ? c->frame_factor : 2;
+        int factor = 2;
         const size_t min_cap = stats ? 0 : c->async_min_cap;
         for (;;) {
             t3d_stats band_stats{};
@@ -2724,7 +2209,6 @@ extern "C" int t3d_render_rows_device(t3d_ctx* c, const t3d_opts* o, int row0, i
                 continue;
             }
             if (rc) { if (rc == T3D_E_CAPACITY) c->err = "trace tree does not fit the node buffers"; return rc; }
-            if (frame_path(c) && factor > c->frame_factor && factor <= (1 << T3D_MAX_BOUNCES)) c->frame_factor = factor;
             if (stats) {
                 uint64_t* dst = &stats->rays_api; const uint64_t* src = &band_stats.rays_api;
                 for (int k = 0; k < T3D_STATS_N_COUNTERS; ++k) dst[k] += src[k];

@@ -61,11 +61,12 @@ def assemble(tiles, height: int, mode: str = "interleaved"):
 _workspace = {}   # receive buffer and frame per gather shape and stream (rank dst only)
 
 
-def gather_frame(tile, height: int, mode: str = "interleaved", group=None, dst: int = 0):
+def gather_frame(tile, height: int, mode: str = "interleaved", group=None, dst: int = 0, slot: int = 0):
     """Collect every rank's tile on rank ``dst`` and return the assembled frame there (``None`` on
     the other ranks).  ``tile`` is a torch tensor [H/G, W, C] on the device the backend moves
     (GPU for nccl/RCCL, CPU for gloo).  Single-process use returns the tile's own frame.  The returned
-    frame is a buffer that the next call with the same shapes overwrites."""
+    frame is a buffer that the next call with the same shapes, stream and ``slot`` overwrites: a caller that
+    keeps several frames in flight gives each chain a slot (and, on a GPU, a stream) of its own."""
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
@@ -80,10 +81,10 @@ def gather_frame(tile, height: int, mode: str = "interleaved", group=None, dst: 
         if tile.is_cuda:
             import torch
             stream_id = torch.cuda.current_stream(tile.device).cuda_stream
-        key = (tuple(tile.shape), tile.dtype, tile.device, world, height, stream_id)
+        key = (tuple(tile.shape), tile.dtype, tile.device, world, height, stream_id, slot, mode)
         ws = _workspace.get(key)
         if ws is None:
-            if len(_workspace) > 8:
+            if len(_workspace) > 16:
                 _workspace.clear()
             stacked = tile.new_empty((world,) + tuple(tile.shape))
             frame = tile.new_empty((height,) + tuple(tile.shape[1:]))

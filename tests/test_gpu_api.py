@@ -9,19 +9,16 @@ from test_gpu_parity import nested_glass_scene
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("path", ["frame", "per_level", "lbvh"])
+@pytest.mark.parametrize("path", ["brute", "lbvh"])
 def test_async_overflow_is_reported_once_and_buffers_grow(monkeypatch, path):
     """An asynchronous call (no stats) whose trace trees outgrow the work buffers cannot say so itself.  The overflow
     stays on record -- also when the frame was cut into several bands, whose counters replace each other -- until the
     next look: t3d_last_call_stats, or the next render call, returns T3D_E_CAPACITY once, and asynchronous calls start
-    with larger buffers from then on.  On all three ways a band is traced: one launch per band (brute force), a launch
-    per tree level (brute force, as the static entry point and single rays do it), the LBVH kernels."""
+    with larger buffers from then on.  On both closest-hit paths."""
     from raytracing_amd import _native
     flat = nested_glass_scene()
     opt = dict(width=24, height=16, bounces=9, samples=2)
-    monkeypatch.setenv("T3D_MEM_BUDGET_MB", "1")       # several bands per frame where memory grows with the band
-    if path == "per_level":
-        monkeypatch.setenv("T3D_PER_LEVEL", "1")
+    monkeypatch.setenv("T3D_MEM_BUDGET_MB", "1")       # several bands per frame
 
     def context():
         c = _native.Context(0)
@@ -32,7 +29,7 @@ def test_async_overflow_is_reported_once_and_buffers_grow(monkeypatch, path):
     ctx = context()
     try:
         want = ctx.render_rows(opt, seed=5)                      # checked call: grows per band as needed
-        assert path == "frame" or want["stats"]["launches"] > 30
+        assert want["stats"]["launches"] > 30
         fresh = context()                                        # a context whose buffers have not grown yet
         try:
             img = _native.pinned_image((16, 24, 3))
@@ -65,18 +62,14 @@ def test_async_overflow_is_reported_once_and_buffers_grow(monkeypatch, path):
         ctx.close()
 
 
-@pytest.mark.parametrize("path", ["frame", "per_level", "lbvh"])
-def test_cancel_stops_inside_a_render_and_the_context_recovers(monkeypatch, path):
-    """The cancel callback is asked before every band and after every launch group that ends a tree level (brute-force
-    scenes traced with one launch per band: after that launch; a large frame is cut into bands of about a million
-    samples while a callback is installed)."""
+@pytest.mark.parametrize("path", ["brute", "lbvh"])
+def test_cancel_stops_inside_a_render_and_the_context_recovers(path):
+    """The cancel callback is asked before every band and after the launches of every tree level."""
     from raytracing_amd import _native
-    if path == "per_level":
-        monkeypatch.setenv("T3D_PER_LEVEL", "1")
     flat = flat_for("config2_cornell_light.json")
     ctx = _native.Context(0)
     try:
-        ctx.set_accel("lbvh" if path == "lbvh" else "brute")
+        ctx.set_accel(path)
         ctx.upload(flat)
         opt = dict(width=160, height=96, bounces=4, samples=2)
         want = ctx.render_rows(opt, seed=1)
@@ -88,8 +81,7 @@ def test_cancel_stops_inside_a_render_and_the_context_recovers(monkeypatch, path
                 return len(polls) > k
             return poll
 
-        per_band = 2 if path == "frame" else 6           # before the band, then after the frame launch / after each of 5 levels
-        for k in ((0, 1) if path == "frame" else (0, 1, 3)):
+        for k in (0, 1, 3):          # before the band, after its first level, after its third
             polls.clear()
             ctx.set_cancel(stop_at(k))
             with pytest.raises(_native.Cancelled):
@@ -98,17 +90,9 @@ def test_cancel_stops_inside_a_render_and_the_context_recovers(monkeypatch, path
             with pytest.raises(_native.NativeError):                 # a cancelled call has no statistics
                 ctx.last_call_stats()
         polls.clear()
-        ctx.set_cancel(lambda: polls.append(1) and False)            # asked, never stops
+        ctx.set_cancel(lambda: polls.append(1) and False)            # asked, never stops: 1 band + 5 levels
         got = ctx.render_rows(opt, seed=1)
-        assert len(polls) == per_band and np.array_equal(got["bgr"], want["bgr"]) and got["stats"]["queries"] == want["stats"]["queries"]
-        if path == "frame":
-            # a frame of 2.4 M samples is cut into bands while somebody may want to stop it
-            big = dict(width=1280, height=960, bounces=1, samples=1)
-            polls.clear()
-            whole = ctx.render_rows(big, seed=1)
-            assert len(polls) >= 4
-            ctx.set_cancel(None)
-            assert np.array_equal(ctx.render_rows(big, seed=1)["bgr"], whole["bgr"])
+        assert len(polls) == 6 and np.array_equal(got["bgr"], want["bgr"]) and got["stats"]["queries"] == want["stats"]["queries"]
         ctx.set_cancel(None)
         polls.clear()
         again = ctx.render_rows(opt, seed=1)

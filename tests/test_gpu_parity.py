@@ -227,11 +227,10 @@ def test_maximum_bounces_and_growing_trees(gpu_ctx, oracle_mod):
     check_growing_trees(gpu_ctx, oracle_mod)
 
 
-@pytest.mark.parametrize("path", ["per_level", "lbvh"])
+@pytest.mark.parametrize("path", ["brute", "lbvh"])
 def test_small_memory_budget_splits_the_frame(gpu_ctx, monkeypatch, path):
     """With a working-set budget of 1 MiB the frame is cut into bands of a few rows, and bands whose trees outgrow the
-    budget are halved: same pixels and the same counts as the frame in one piece.  (On the two paths whose work memory
-    grows with the band: a launch per tree level, and the LBVH kernels.)"""
+    budget are halved: same pixels and the same counts as the frame in one piece, on both closest-hit paths."""
     from raytracing_amd import _native
     flat = nested_glass_scene()
     opt = dict(width=24, height=16, bounces=9, samples=2)
@@ -243,8 +242,6 @@ def test_small_memory_budget_splits_the_frame(gpu_ctx, monkeypatch, path):
     finally:
         roomy.close()
     monkeypatch.setenv("T3D_MEM_BUDGET_MB", "1")
-    if path == "per_level":
-        monkeypatch.setenv("T3D_PER_LEVEL", "1")
     small = _native.Context(0)
     try:
         small.set_accel("lbvh" if path == "lbvh" else "brute")

@@ -76,3 +76,36 @@ def test_gather_two_ranks_gloo(mode):
         ret = mgr.dict()
         mp.spawn(_worker, args=(world, _free_port(), mode, ret), nprocs=world, join=True)
         assert ret.get("ok") is True
+
+
+def _worker_in_flight(rank, world, port, ret):
+    """Three frames in flight: three gathers whose frames are all still wanted when the last one returns."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        H, W = 24, 5
+        t = partition_rows(H, world, rank, "interleaved")
+        frames = []
+        for k in range(3):      # chain k renders "frame k": pixel value = image row + 60 k
+            tile = (torch.tensor(list(t.rows()), dtype=torch.uint8) + 60 * k).view(-1, 1, 1).expand(t.nrows, W, 3).contiguous()
+            frames.append(gather_frame(tile, H, "interleaved", slot=k))
+        again = gather_frame(torch.zeros((t.nrows, W, 3), dtype=torch.uint8), H, "interleaved", slot=1)   # chain 1's next frame
+        if rank == 0:
+            rows = torch.arange(H, dtype=torch.uint8)
+            ok = all(f is not None for f in frames)
+            ok = ok and len({f.data_ptr() for f in frames}) == 3                     # a buffer per chain
+            ok = ok and bool((frames[0][:, 0, 0] == rows).all()) and bool((frames[2][:, 2, 1] == rows + 120).all())
+            ok = ok and again.data_ptr() == frames[1].data_ptr() and bool((frames[1] == 0).all())   # ... reused by that chain only
+            ret["ok"] = ok
+        else:
+            assert all(f is None for f in frames) and again is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gathers_of_several_frames_in_flight_gloo():
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_in_flight, args=(world, _free_port(), ret), nprocs=world, join=True)
+        assert ret.get("ok") is True

@@ -26,8 +26,23 @@ if "--traffic-json" in sys.argv:
         levels = sum(len(cs.get(counter, [])) for k, cs in acc.items() if k.startswith(("k_level", "k_bvh_trace")))
         return (sum(vals) / levels, levels) if levels else (None, 0)
     (fk, nf), (wk, nw) = level_sum("FETCH_SIZE"), level_sum("WRITE_SIZE")
+    # executed vector-ALU work of one tree level: wave instructions (SQ_INSTS_VALU) and how many of a wave's 64 lanes an
+    # instruction had active on average (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU; both count 4 cycles per instruction)
+    (iv, ni), (tc, _), (ac, _) = level_sum("SQ_INSTS_VALU"), level_sum("SQ_THREAD_CYCLES_VALU"), level_sum("SQ_ACTIVE_INST_VALU")
+    extra = {}
+    if iv is not None:
+        extra["valu_wave_insts_per_launch"] = int(iv)
+        extra["valu_launches_sampled"] = ni
+    if tc is not None and ac:
+        extra["valu_active_lanes"] = round(tc / ac, 2)
+    import datetime, subprocess
+    try:
+        extra["commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except OSError:
+        extra["commit"] = None
+    extra["date"] = datetime.date.today().isoformat()
     if fk is not None and wk is not None:
         json.dump({"kernel": "k_level", "workload": workload, "fetch_size_kib_per_launch": round(fk, 1),
                    "write_size_kib_per_launch": round(wk, 1), "fetch_correction": 2.0,
-                   "hbm_bytes_per_launch": int((2.0 * fk + wk) * 1024), "launches_sampled": [nf, nw]},
+                   "hbm_bytes_per_launch": int((2.0 * fk + wk) * 1024), "launches_sampled": [nf, nw], **extra},
                   open(out, "w"), indent=1)
