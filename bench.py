@@ -39,9 +39,10 @@ HBM_PEAK_GBS = 8000.0
 
 
 def pmc_traffic(workload):
-    """HBM bytes per k_level launch from the newest committed counter run (profiles/*_pmc_traffic.json, made by
-    tools/gpu_pmc.sh + tools/pmc_summary.py); None when there is none for this workload.  Counters cannot be
-    read from inside this process, so this is the one roofline field that is not measured live."""
+    """Hardware counters of one tree level's launches from the newest committed counter run (profiles/*_pmc_traffic.json,
+    made by tools/gpu_pmc.sh + tools/pmc_summary.py): HBM bytes, executed vector-ALU wave instructions, active lanes per
+    instruction; None when there is none for this workload.  Counters cannot be read from inside this process, so these
+    are the roofline fields that are not measured live; the file's commit and date go into the line with them."""
     import glob
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
@@ -54,12 +55,12 @@ def pmc_traffic(workload):
     return best
 
 
-def cpu_baseline(flat, options, seed, row_step=1):
+def cpu_baseline(flat, options, seed, row_step=1, nthreads=None):
     """Oracle timed on host threads: every `row_step`-th image row of the same frame, rows dealt
     round-robin to the threads (ctypes releases the GIL during the C call)."""
     from oracle import oracle
     oracle.lib()
-    nthreads = max(1, min(16, os.cpu_count() or 1))
+    nthreads = nthreads or max(1, min(16, os.cpu_count() or 1))
     H = options["height"]
     if row_step <= 0:
         row_step = max(1, H // nthreads)   # one row per thread
@@ -97,6 +98,9 @@ def main():
                     help="independent frames traced at the same time, each with a context and a stream of its own "
                          "(0: one for LBVH scenes; brute-force scenes two with one rank, three with two, four with more)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (RCCL over xGMI, one GPU per rank) or gloo: tiles gathered through host memory, and ranks share the "
+                         "visible GPUs when there are fewer of them than ranks -- a rehearsal of the several-rank path on a small box")
     ap.add_argument("--cpu-row-step", type=int, default=0, help="CPU baseline renders every n-th row (0: every row for the headline workload, one row per thread otherwise)")
     args = ap.parse_args()
 
@@ -106,14 +110,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    gloo = world > 1 and args.dist_backend == "gloo"
+    if gloo:
+        local_rank %= max(1, torch.cuda.device_count())
     if world > 1:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     elif args.gpus != 1:
         print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
         sys.exit(2)
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}", file=sys.stderr)
+        sys.exit(2)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
+    comm_device = torch.device("cpu") if gloo else device
 
     from raytracing_amd import _native
     from raytracing_amd.tiles import gather_frame, partition_rows, sum_counters
@@ -151,7 +165,11 @@ def main():
         torch.cuda.set_stream(streams[k])
         st = ctxs[k].render_rows_device(options, seed, tile.row0, tile.nrows, outs[k].data_ptr(), stream=streams[k].cuda_stream,
                                         want_stats=want_stats, row_stride=tile.stride)
-        frame = gather_frame(outs[k], H, args.partition)
+        if gloo:
+            streams[k].synchronize()
+            frame = gather_frame(outs[k].cpu(), H, args.partition, slot=k)
+        else:
+            frame = gather_frame(outs[k], H, args.partition, slot=k)
         return st, frame
 
     def sync():
@@ -196,12 +214,12 @@ def main():
         if not torch.equal(outs[k], outs[0]):
             raise RuntimeError(f"the tile of chain {k} differs from the tile rendered alone")
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     keys = ["queries", "rays_api", "tri_tests", "sphere_tests", "aabb_tests", "shadow_queries", "trace_queries", "nodes"]
-    totals = dict(zip(keys, sum_counters([first_stats[k] for k in keys], device=device)))
+    totals = dict(zip(keys, sum_counters([first_stats[k] for k in keys], device=comm_device)))
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -218,13 +236,18 @@ def main():
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "width": W, "height": H, "bounces": options["bounces"],
+            "config": {"workload": args.workload, "ranks": world, "collective": ("gloo gather through host memory (rehearsal)" if gloo else
+                                                                               ("RCCL gather" if world > 1 else "none")),
+                       "width": W, "height": H, "bounces": options["bounces"],
                        "samples": options["samples"], "triangles": T, "spheres_and_lights": S,
                        "lights": int(len(flat.light_strength)), "partition": f"{args.partition} rows x{world}",
                        "frames_in_flight": F,
                        "queries_per_frame": totals["queries"], "rendered_rays_per_frame": totals["rays_api"]},
             "roofline": {"bound": "valu", "kernel": "k_level", "achieved": round(achieved, 3), "peak": FP32_VALU_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4), "traffic": None,
+                         # frac counts the work a brute-force Moeller-Trumbore loop would do for these queries, not the
+                         # instructions this kernel executes (plane grouping and whole-wave skips do the same tests in fewer)
+                         "flops": "algorithmic: 51 per ray-triangle test, 19 per ray-sphere test; not executed instructions",
                          "launches_per_frame": last["n_k_level"],
                          "avg_launch_ms": round(last["ms_k_level"] / max(1, last["n_k_level"]), 5),
                          "flops_per_launch": flops / max(1, last["n_k_level"]),
@@ -239,29 +262,65 @@ def main():
                          "frac": round(flops / (ms_per_step * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 4)},
         }
         tr = pmc_traffic(args.workload) if world == 1 else None
-        if tr:
-            line["roofline"]["traffic"] = tr[0]["hbm_bytes_per_launch"]
-            line["roofline"]["traffic_source"] = "profiles/" + tr[1]
+
+        def counters_into(roof):
+            """Counter-derived fields (from the committed run, see pmc_traffic) next to the live ones."""
+            if not tr:
+                return
+            d = tr[0]
+            roof["traffic"] = d["hbm_bytes_per_launch"]
+            roof["traffic_source"] = f"profiles/{tr[1]} (commit {d.get('commit')}, {d.get('date')})"
+            if d.get("valu_wave_insts_per_launch") and roof.get("avg_launch_ms"):
+                # executed vector-ALU instructions against the issue rate of the chip: one wave instruction per SIMD every 4 cycles
+                issue_peak = 1024 * 2.4e9 / 4
+                rate = d["valu_wave_insts_per_launch"] / (roof["avg_launch_ms"] * 1e-3)
+                roof["valu_issue_frac"] = round(rate / issue_peak, 4)
+                roof["valu_wave_insts_per_launch"] = d["valu_wave_insts_per_launch"]
+            if d.get("valu_active_lanes"):
+                roof["valu_active_lanes_of_64"] = d["valu_active_lanes"]
+
+        counters_into(line["roofline"])
         if last["aabb_tests"] > 0:
-            # LBVH traversal: memory roofline.  Algorithmic bytes: 64 B per node record visited (four quantised boxes
-            # and their links), 64 B per triangle or sphere test (one leaf record).
+            # LBVH traversal.  The records a query visits (64 B per node record: four quantised boxes and their links; 64 B
+            # per triangle or sphere test: one leaf record) are mostly served by the caches -- their rate can exceed the
+            # HBM peak, so HBM is not the roof.  What bounds the kernels is vector-ALU issue at part-filled waves: the
+            # roofline is executed wave instructions per second against the chip's issue rate (counters of a committed
+            # run, duration live), with the memory side reported beside it.
             nbytes = 64.0 * (last["aabb_tests"] / 4) + 64.0 * last["tri_tests"] + 64.0 * last["sphere_tests"]
             gbs = nbytes / level_s / 1e9 if level_s > 0 else 0.0
-            line["roofline"] = {"bound": "hbm", "kernel": "k_level (LBVH traversal)", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-                                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                                "launches_per_frame": last["n_k_level"],
-                                "avg_launch_ms": round(last["ms_k_level"] / max(1, last["n_k_level"]), 5),
-                                "bytes_per_launch": nbytes / max(1, last["n_k_level"]),
-                                "nodes_visited_per_query": round(last["aabb_tests"] / 4 / max(1, last["queries"]), 2),
-                                "tri_tests_per_query": round(last["tri_tests"] / max(1, last["queries"]), 2),
-                                "deep_stack_pushes": last["bvh_deep_pushes"],
-                                "frame_device_ms": round(last["ms_device"], 4), "resolve_ms": round(last["ms_resolve"], 4)}
-            if tr:
-                line["roofline"]["traffic"] = tr[0]["hbm_bytes_per_launch"]
-                line["roofline"]["traffic_source"] = "profiles/" + tr[1]
+            n_launch = max(1, last["n_k_level"])
+            roof = {"bound": "valu-issue", "kernel": "k_bvh_trace + k_bvh_process + k_bvh_shadow (one tree level)",
+                    "achieved": None, "peak": round(1024 * 2.4e9 / 4 / 1e9, 1), "unit": "G wave-instructions/s", "frac": None, "traffic": None,
+                    "launches_per_frame": last["n_k_level"], "avg_launch_ms": round(last["ms_k_level"] / n_launch, 5),
+                    "nodes_visited_per_query": round(last["aabb_tests"] / 4 / max(1, last["queries"]), 2),
+                    "tri_tests_per_query": round(last["tri_tests"] / max(1, last["queries"]), 2),
+                    "deep_stack_pushes": last["bvh_deep_pushes"],
+                    "frame_device_ms": round(last["ms_device"], 4), "resolve_ms": round(last["ms_resolve"], 4),
+                    "memory": {"algorithmic_bytes_per_launch": nbytes / n_launch, "algorithmic_gbs": round(gbs, 1),
+                               "hbm_peak_gbs": HBM_PEAK_GBS, "note": "record bytes requested by the lanes; most are cache hits"}}
+            counters_into(roof)
+            if roof.get("valu_issue_frac") is not None:
+                roof["frac"] = roof["valu_issue_frac"]
+                roof["achieved"] = round(roof["valu_wave_insts_per_launch"] / (roof["avg_launch_ms"] * 1e-3) / 1e9, 1)
+                if roof.get("traffic"):
+                    roof["memory"]["fabric_bytes_per_launch"] = roof["traffic"]
+                    roof["memory"]["cache_hit_ratio"] = round(1.0 - roof["traffic"] / (nbytes / n_launch), 3)
+            line["roofline"] = roof
             line["metric"] = f"Mrays/s (primary+secondary closest-hit queries), {args.workload}"
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(flat, options, seed, row_step=args.cpu_row_step or (1 if args.workload == "cornell_1080p_b4" else 0))
+            headline = args.workload == "cornell_1080p_b4"
+            base = cpu_baseline(flat, options, seed, row_step=args.cpu_row_step or (1 if headline else 0))
+            if headline:
+                # the same oracle on one thread (every 16th row of the frame), and the reference's own small case
+                # (cornellScene.json 160x120, default bounces) on one thread and on all of them
+                one = cpu_baseline(flat, options, seed, row_step=max(16, args.cpu_row_step), nthreads=1)
+                base["one_thread"] = {k: one[k] for k in ("value", "unit", "cores", "sample", "seconds")}
+                small_flat, small_opt = get_flat_workload("cornell_160x120_b1")
+                m1 = cpu_baseline(small_flat, small_opt, seed, row_step=1, nthreads=1)
+                m1_all = cpu_baseline(small_flat, small_opt, seed, row_step=1)
+                base["cornell_160x120_b1"] = {"one_thread": {k: m1[k] for k in ("value", "unit", "cores", "sample", "seconds")},
+                                              "all_threads": {k: m1_all[k] for k in ("value", "unit", "cores", "sample", "seconds")}}
+            line["cpu_baseline"] = base
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

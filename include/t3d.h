@@ -232,6 +232,11 @@ int t3d_render_rows_device_static(t3d_ctx* ctx, const t3d_opts* opts, int row0, 
  * serves Rendered.traces[(x, y)][sample] lazily, T3DR.py:1210-1216).  Returns the number of
  * nodes written (>= 0), nodes in depth-first order with the bounce child before the transmit
  * child, or a negative error.
+ * One deviation from the reference, here and in t3d_trace_ray and the render calls: an emitter (Light object or
+ * emissive face) hit by the initial ray is a leaf whatever opts->lights says.  The reference makes it one only when
+ * `lights` is true (T3DR.py:973) and otherwise traces children below it that computeColor never looks at
+ * (T3DR.py:1014-1041 return first): pixels and Rendered.rays are the same, the tree and the counters queries /
+ * trace_queries / nodes / level_rays lack those never-shaded rays.
  */
 int t3d_trace_pixel(t3d_ctx* ctx, const t3d_opts* opts, int x, int y, int sample, t3d_node* nodes,
                     int capacity);

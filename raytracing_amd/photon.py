@@ -12,6 +12,9 @@ Differences a caller can observe, all deliberate:
 * random directions for bounce()/transmit() come from the keyed generator in ``keyed_rng`` (option
   ``seed``, default 0), so an image is reproducible and independent of how rows are split.
 * ``Rendered.traces`` is a lazy mapping: ``traces[(x, y)]`` re-traces that pixel on the GPU.
+* with ``lights`` False an emitter hit by the initial ray is still a leaf of the trace tree (the reference traces
+  children below it that ``computeColor`` never looks at, T3DR.py:973, 1014-1041): same pixels and ``rays``, smaller
+  trees from ``trace`` / ``traces``.
 * extra option keys: ``device`` (HIP device index, default 0), ``seed``, ``gpus`` (render the frame on that many
   devices at once, rows interleaved; must divide ``height``) and ``devices`` (which ones).
 """

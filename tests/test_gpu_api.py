@@ -246,3 +246,39 @@ def test_single_ray_trees_with_many_lights_need_little_memory(gpu_ctx, oracle_mo
     assert sorted(n.heap for n in nodes) == sorted(want) and len(nodes) >= 1
     for n in nodes:
         assert np.allclose(list(n.color), want[n.heap]["color"], atol=0.05)
+
+
+def _run_bench_ranks(n, extra):
+    import json
+    import os
+    import subprocess
+    import sys
+    from test_tiles import _free_port
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_with_two_ranks_rehearsed_on_one_gpu():
+    """bench.py as the driver starts it for N > 1 -- torch.distributed.run, one process per rank, interleaved rows,
+    several frames in flight per rank, a gather per frame, counters summed, time the maximum over ranks -- with the
+    gloo backend, so that two ranks can share the one GPU a test box has (RCCL refuses that)."""
+    d = _run_bench_ranks(2, ["--dist-backend", "gloo"])
+    assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["scaling"] == "strong" and d["steps"] == 3
+    assert d["config"]["partition"] == "interleaved rows x2" and "gloo" in d["config"]["collective"]
+    assert d["config"]["queries_per_frame"] == 17874992          # both halves of the frame, summed over the ranks
+    assert d["value"] > 0 and "cpu_baseline" not in d          # the CPU baseline is a one-rank field
+
+
+def test_bench_with_two_ranks_over_rccl():
+    """The same with the RCCL backend, one GPU per rank: runs where two GPUs are visible."""
+    from raytracing_amd import _native
+    if _native.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    d = _run_bench_ranks(2, [])
+    assert d["n_gpus"] == 2 and d["config"]["collective"] == "RCCL gather" and d["config"]["queries_per_frame"] == 17874992
