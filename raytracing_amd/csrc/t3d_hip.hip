@@ -43,6 +43,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <cmath>
 #include <map>
 #include <mutex>
@@ -105,6 +106,7 @@ struct DevGeo {
     float box_lo[3], box_hi[3];  // bounds of every triangle and sphere, padded outward
 };
 struct DevBvh {
+    int* spill;            // [traversal waves][T3D_BVH_DEEP_STACK][64]: stack entries beyond the LDS part, entry e of a lane at 64 e + lane
     const float4* nodes;   // [n_prims - 1] x 4 rows, see t3d_lbvh.h; null when the scene is traced by brute force
     const float4* leaves;  // [n_prims] x 4 rows in sorted order, see k_lbvh_leaves; triangles: (n.xyz, -n.v0), (a.xyz, aw),
                            // (b.xyz, bw) with u = a.P + aw, v = b.P + bw
@@ -404,7 +406,7 @@ __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0
 
 // ------------------------------------------------------------------------------------------------
 // closest hit through the LBVH (t3d_lbvh.h): one ray per lane, near child first; the first T3D_BVH_LDS_STACK entries
-// of a lane's stack live in LDS, deeper ones (rare) in private memory.
+// of a lane's stack live in LDS, deeper ones (rare) in a spill area in global memory that belongs to the wave.
 // Same acceptance rules as the brute-force loop; equal distances go to the primitive that comes first in
 // the scene's object / face order, whatever order the traversal meets them in.
 // ------------------------------------------------------------------------------------------------
@@ -451,8 +453,9 @@ __device__ __forceinline__ void bvh_begin(BvhLane& s, V3 o, V3 d, bool lights, b
 
 // One step: a node record (four slab tests, entered slots pushed far to near, nearest descended into) or a leaf
 // (one triangle or sphere).  Returns true when nothing is left on the stack.
-// lds: this lane's column of the wave's LDS stack (entry e at lds[64 e]); deep: entries beyond it
-__device__ __forceinline__ bool bvh_step(const DevScene& sc, BvhLane& s, int* lds, int (&deep)[T3D_BVH_DEEP_STACK], BvhCount& bc,
+// lds: this lane's column of the wave's LDS stack (entry e at lds[64 e]); deep: this lane's column of the wave's spill
+// area for the entries beyond it (entry e at deep[64 (e - T3D_BVH_LDS_STACK)])
+__device__ __forceinline__ bool bvh_step(const DevScene& sc, BvhLane& s, int* lds, int* __restrict__ deep, BvhCount& bc,
                                          int* stack_overflow, int* sticky) {
     const V3 o = s.o, d = s.d, inv = s.inv, oi = s.oi;
     auto pop = [&]() {
@@ -460,7 +463,7 @@ __device__ __forceinline__ bool bvh_step(const DevScene& sc, BvhLane& s, int* ld
         s.node = s.top;
         --s.sp;
         const int e = s.sp > 0 ? s.sp - 1 : 0;
-        s.top = e < T3D_BVH_LDS_STACK ? lds[64 * e] : deep[e - T3D_BVH_LDS_STACK];
+        s.top = e < T3D_BVH_LDS_STACK ? lds[64 * e] : deep[64 * (e - T3D_BVH_LDS_STACK)];
     };
     if (s.node >= 0 && s.node != BVH_DONE) {
         const float4* __restrict__ rec = sc.bvh.nodes + 4 * (size_t)s.node;
@@ -474,17 +477,22 @@ __device__ __forceinline__ bool bvh_step(const DevScene& sc, BvhLane& s, int* ld
         const uint32_t qlx = __float_as_uint(r1.x), qhx = __float_as_uint(r1.y), qly = __float_as_uint(r1.z), qhy = __float_as_uint(r1.w);
         const uint32_t qlz = __float_as_uint(r2.x), qhz = __float_as_uint(r2.y);
         const int base01 = __float_as_int(r2.z), base23 = __float_as_int(r2.w);
+        // which plane of a slab the ray meets first depends on the sign of its direction only: the near planes of all
+        // four slots are the lo bytes where the ray travels up the axis and the hi bytes where it travels down
+        const uint32_t nx4 = inv.x < 0.0f ? qhx : qlx, fx4 = inv.x < 0.0f ? qlx : qhx;
+        const uint32_t ny4 = inv.y < 0.0f ? qhy : qly, fy4 = inv.y < 0.0f ? qly : qhy;
+        const uint32_t nz4 = inv.z < 0.0f ? qhz : qlz, fz4 = inv.z < 0.0f ? qlz : qhz;
         // a slot is entered while its slab interval reaches the best distance so far (<=: equal distances must all
         // be seen); empty slots never are
         float tn[4];
         int ln[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float ax = fmaf((float)((qlx >> (8 * k)) & 255u), sx, cx), bx = fmaf((float)((qhx >> (8 * k)) & 255u), sx, cx);
-            const float ay = fmaf((float)((qly >> (8 * k)) & 255u), sy, cy), by = fmaf((float)((qhy >> (8 * k)) & 255u), sy, cy);
-            const float az = fmaf((float)((qlz >> (8 * k)) & 255u), sz, cz), bz = fmaf((float)((qhz >> (8 * k)) & 255u), sz, cz);
-            const float near = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-            const float far = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), s.best)) * 1.0000004f;
+            const float ax = fmaf((float)((nx4 >> (8 * k)) & 255u), sx, cx), bx = fmaf((float)((fx4 >> (8 * k)) & 255u), sx, cx);
+            const float ay = fmaf((float)((ny4 >> (8 * k)) & 255u), sy, cy), by = fmaf((float)((fy4 >> (8 * k)) & 255u), sy, cy);
+            const float az = fmaf((float)((nz4 >> (8 * k)) & 255u), sz, cz), bz = fmaf((float)((fz4 >> (8 * k)) & 255u), sz, cz);
+            const float near = fmaxf(fmaxf(ax, ay), fmaxf(az, 0.0f));
+            const float far = fminf(fminf(bx, by), fminf(bz, s.best)) * 1.0000004f;
             const bool present = (meta & (1u << (24 + k))) != 0u;
             tn[k] = (near <= far && present) ? near : __builtin_inff();   // +inf: not entered
             const int leaf = ((int)(meta << (3 - k))) >> 31;                 // bit 28 + k, spread: -1 for a leaf, else 0
@@ -511,7 +519,7 @@ __device__ __forceinline__ bool bvh_step(const DevScene& sc, BvhLane& s, int* ld
             for (int k = 3; k >= 1; --k) {
                 if (tn[k] < __builtin_inff()) {
                     if (s.sp < T3D_BVH_LDS_STACK) { s.top = ln[k]; lds[64 * s.sp++] = s.top; }
-                    else if (s.sp < T3D_BVH_STACK) { s.top = ln[k]; deep[s.sp++ - T3D_BVH_LDS_STACK] = s.top; bc.deep++; }
+                    else if (s.sp < T3D_BVH_STACK) { s.top = ln[k]; deep[64 * (s.sp++ - T3D_BVH_LDS_STACK)] = s.top; bc.deep++; }
                     else { *stack_overflow = 1; if (sticky) sticky[1] = 1; }
                 }
             }
@@ -575,11 +583,10 @@ __device__ __forceinline__ bool bvh_step(const DevScene& sc, BvhLane& s, int* ld
 
 // Closest hit of one ray per lane; every lane runs until its own ray is finished.
 __device__ __forceinline__ void bvh_closest(const DevScene& sc, const DevSphere* __restrict__ spheres, V3 o, V3 d, bool active,
-                                            bool lights, bool back_cull, Hit& out, BvhCount& bc, int* stack_overflow, int* lds) {
+                                            bool lights, bool back_cull, Hit& out, BvhCount& bc, int* stack_overflow, int* lds, int* deep) {
     out.t = __builtin_inff(); out.prim = -1; out.back = 0;
     if (!active) return;
     BvhLane s;
-    int deep[T3D_BVH_DEEP_STACK];
     bvh_begin(s, o, d, lights, back_cull);
     while (!bvh_step(sc, s, lds, deep, bc, stack_overflow, nullptr)) {}
     out.t = s.best; out.prim = s.prim; out.back = s.back;
@@ -1120,7 +1127,7 @@ __global__ __launch_bounds__(T3D_BLOCK, T3D_BVH_WAVES) void k_bvh_trace(DevScene
     __shared__ int lds_stack[T3D_WAVES][T3D_BVH_LDS_STACK][64];
     int* lds = &lds_stack[threadIdx.x >> 6][0][lane];
     BvhLane st;
-    int deep[T3D_BVH_DEEP_STACK];
+    int* deep = sc.bvh.spill + ((size_t)gw * T3D_BVH_DEEP_STACK) * 64 + lane;
     BvhCount bc{0, 0, 0, 0};
     bool have = false;     // a ray is in flight in this lane
     bool pending = false;  // a finished ray's result is still in st
@@ -1199,7 +1206,7 @@ __global__ __launch_bounds__(T3D_BLOCK, T3D_BVH_WAVES) void k_bvh_shadow(DevScen
     __shared__ int lds_stack[T3D_WAVES][T3D_BVH_LDS_STACK][64];
     int* lds = &lds_stack[threadIdx.x >> 6][0][lane];
     BvhLane st;
-    int deep[T3D_BVH_DEEP_STACK];
+    int* deep = sc.bvh.spill + ((size_t)gw * T3D_BVH_DEEP_STACK) * 64 + lane;
     BvhCount bc{0, 0, 0, 0};
     bool have = false, pending = false;
     int my_node = 0, my_light = 0;
@@ -1297,39 +1304,44 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_closest(DevScene sc, GEO_PARAMS, 
                                                        const float* __restrict__ dirs, int lights, int back_cull,
                                                        int32_t* out_obj, int32_t* out_face, float* out_t, int32_t* out_dir,
                                                        float* out_normal) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool active = i < n;
-    int j = active ? i : 0;
-    V3 o = mk(origins[3 * j], origins[3 * j + 1], origins[3 * j + 2]);
-    V3 d = normalize(mk(dirs[3 * j], dirs[3 * j + 1], dirs[3 * j + 2]));
-    Hit h, h_dup;
-    if (sc.bvh.nodes) {  // uniform over the launch
-        __shared__ int lds_stack[T3D_WAVES][T3D_BVH_LDS_STACK][64];
-        BvhCount bc{0, 0, 0, 0};
-        int overflow = 0;
-        bvh_closest(sc, spheres, o, d, active, lights != 0, back_cull != 0, h, bc, &overflow, &lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63]);
-    } else {
-        closest_hit2(GEO_ARGS, sc.geo, o, d, o, d, lights != 0, back_cull != 0, back_cull != 0, h, h_dup);
-    }
-    if (!active) return;
-    int obj = -1, face = -1, dirflag = 0;
-    V3 N = mk(0, 0, 0);
-    if (h.prim >= 0) {
-        if (h.prim < sc.n_tris) {
-            int4 meta = sc.tri_meta[h.prim];
-            float4 rn = sc.tri_n[h.prim];
-            obj = meta.x; face = meta.y; N = mk(rn.x, rn.y, rn.z);
-            dirflag = (dot(N, d) < 0.0f) ? 0 : 1;
+    __shared__ int lds_stack[T3D_WAVES][T3D_BVH_LDS_STACK][64];
+    // the grid is bounded (every wave owns a piece of the traversal spill area): blocks walk the rays in strides
+    for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
+        const int i = base + threadIdx.x;
+        const bool active = i < n;
+        const int j = active ? i : 0;
+        V3 o = mk(origins[3 * j], origins[3 * j + 1], origins[3 * j + 2]);
+        V3 d = normalize(mk(dirs[3 * j], dirs[3 * j + 1], dirs[3 * j + 2]));
+        Hit h, h_dup;
+        if (sc.bvh.nodes) {  // uniform over the launch
+            BvhCount bc{0, 0, 0, 0};
+            int overflow = 0;
+            const int gw = blockIdx.x * T3D_WAVES + (threadIdx.x >> 6);
+            bvh_closest(sc, spheres, o, d, active, lights != 0, back_cull != 0, h, bc, &overflow, &lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63],
+                        sc.bvh.spill + ((size_t)gw * T3D_BVH_DEEP_STACK) * 64 + (threadIdx.x & 63));
         } else {
-            DevSphere sp = spheres[h.prim - sc.n_tris];
-            V3 P = madd(o, d, h.t);
-            obj = sp.obj; dirflag = h.back;
-            N = normalize(mk(P.x - sp.cx, P.y - sp.cy, P.z - sp.cz));
+            closest_hit2(GEO_ARGS, sc.geo, o, d, o, d, lights != 0, back_cull != 0, back_cull != 0, h, h_dup);
         }
+        if (!active) continue;
+        int obj = -1, face = -1, dirflag = 0;
+        V3 N = mk(0, 0, 0);
+        if (h.prim >= 0) {
+            if (h.prim < sc.n_tris) {
+                int4 meta = sc.tri_meta[h.prim];
+                float4 rn = sc.tri_n[h.prim];
+                obj = meta.x; face = meta.y; N = mk(rn.x, rn.y, rn.z);
+                dirflag = (dot(N, d) < 0.0f) ? 0 : 1;
+            } else {
+                DevSphere sp = spheres[h.prim - sc.n_tris];
+                V3 P = madd(o, d, h.t);
+                obj = sp.obj; dirflag = h.back;
+                N = normalize(mk(P.x - sp.cx, P.y - sp.cy, P.z - sp.cz));
+            }
+        }
+        out_obj[i] = obj; out_face[i] = face; out_dir[i] = dirflag;
+        out_t[i] = h.prim >= 0 ? h.t : __builtin_nanf("");
+        if (out_normal) { out_normal[3 * i] = N.x; out_normal[3 * i + 1] = N.y; out_normal[3 * i + 2] = N.z; }
     }
-    out_obj[i] = obj; out_face[i] = face; out_dir[i] = dirflag;
-    out_t[i] = h.prim >= 0 ? h.t : __builtin_nanf("");
-    if (out_normal) { out_normal[3 * i] = N.x; out_normal[3 * i + 1] = N.y; out_normal[3 * i + 2] = N.z; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1384,7 +1396,7 @@ struct t3d_ctx {
     // scene buffers
     DevScene sc{};
     void* d_planes = nullptr; void* d_plane_first = nullptr; void* d_tri_uv = nullptr; void* d_tri_n = nullptr;
-    void* d_bvh_nodes = nullptr; void* d_bvh_leaves = nullptr;
+    void* d_bvh_nodes = nullptr; void* d_bvh_leaves = nullptr; void* d_bvh_spill = nullptr;
     int accel = T3D_ACCEL_AUTO;   // t3d_set_accel
     bool use_bvh = false;         // the uploaded scene is traced through the LBVH
     void* d_tri_meta = nullptr; void* d_spheres = nullptr; void* d_lights = nullptr;
@@ -1503,7 +1515,8 @@ extern "C" int t3d_create(int device, t3d_ctx** out) {
 
 static void free_scene(t3d_ctx* c) {
     hipFree(c->d_planes); hipFree(c->d_plane_first); hipFree(c->d_tri_uv); hipFree(c->d_tri_n);
-    hipFree(c->d_bvh_nodes); hipFree(c->d_bvh_leaves); c->d_bvh_nodes = c->d_bvh_leaves = nullptr; c->use_bvh = false;
+    hipFree(c->d_bvh_nodes); hipFree(c->d_bvh_leaves); hipFree(c->d_bvh_spill);
+    c->d_bvh_nodes = c->d_bvh_leaves = c->d_bvh_spill = nullptr; c->use_bvh = false;
     hipFree(c->d_tri_meta); hipFree(c->d_spheres); hipFree(c->d_lights);
     hipFree(c->d_shaders); hipFree(c->d_obj_ior);
     c->d_planes = c->d_plane_first = c->d_tri_uv = c->d_tri_n = nullptr;
@@ -1789,10 +1802,14 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
         hipFree(d_verts); hipFree(d_tri_ab);
         if (e != hipSuccess) { c->err = std::string("t3d_upload_scene: LBVH build failed: ") + hipGetErrorString(e); return T3D_E_DEVICE; }
         c->d_bvh_nodes = nodes; c->d_bvh_leaves = leaves;
+        // deep ends of traversal stacks, one piece per wave the traversal kernels can have in flight (never touched by the
+        // benchmark workloads, whose stacks stay within the LDS part)
+        HIPCHK(c, hipMalloc(&c->d_bvh_spill, sizeof(int) * 64 * T3D_BVH_DEEP_STACK * (size_t)c->n_sm * T3D_BVH_WAVES * T3D_WAVES));
         c->use_bvh = true;
     }
     DevScene& d = c->sc;
     d.bvh.nodes = (const float4*)c->d_bvh_nodes; d.bvh.leaves = (const float4*)c->d_bvh_leaves; d.bvh.n_prims = n_prims;
+    d.bvh.spill = (int*)c->d_bvh_spill;
     d.geo.axis_end[0] = axis_count[0]; d.geo.axis_end[1] = axis_count[0] + axis_count[1]; d.geo.axis_end[2] = (int)G;
     d.geo.n_tris = s->n_tris; d.geo.n_spheres = (int)spheres.size();
     {   // scene bounds for the camera-ray pre-test, padded outward by 1e-4 of their size
@@ -2602,7 +2619,8 @@ extern "C" int t3d_closest_hits(t3d_ctx* c, int n, const float* origins, const f
     int32_t* h_obj = (int32_t*)(base + 3 * n3 + n1); int32_t* h_face = (int32_t*)(base + 3 * n3 + 2 * n1); int32_t* h_dir = (int32_t*)(base + 3 * n3 + 3 * n1);
     memcpy(h_o, origins, n3);
     memcpy(h_d, dirs, n3);
-    hipLaunchKernelGGL(k_closest, dim3((n + T3D_BLOCK - 1) / T3D_BLOCK), dim3(T3D_BLOCK), 0, c->stream, c->sc, (const float4*)c->d_planes,
+    const int pick_blocks = (int)std::min<size_t>(((size_t)n + T3D_BLOCK - 1) / T3D_BLOCK, (size_t)c->n_sm * T3D_BVH_WAVES);
+    hipLaunchKernelGGL(k_closest, dim3(pick_blocks), dim3(T3D_BLOCK), 0, c->stream, c->sc, (const float4*)c->d_planes,
                        (const int*)c->d_plane_first, (const float4*)c->d_tri_uv, (const DevSphere*)c->d_spheres, n, h_o, h_d, lights, back_cull, h_obj, h_face, h_t, h_dir, h_n);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
