@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define T3D_ABI_VERSION 3
+#define T3D_ABI_VERSION 4
 
 enum {
     T3D_OK = 0,
@@ -115,6 +115,10 @@ typedef struct t3d_stats {
     uint64_t level_nodes[T3D_STATS_MAX_LEVELS];  /* shaded nodes created at the level                */
     double level_ms[T3D_STATS_MAX_LEVELS];       /* time spent tracing the level                     */
     uint64_t bvh_deep_pushes; /* LBVH path: traversal-stack entries that did not fit the per-lane LDS part   */
+    uint64_t shadow_culled;   /* shadow rays answered without being traced: the light term of getDirectLight
+                                 (T3DR.py:880) is zero whatever the ray hits when the surface faces away from the
+                                 light and shows the camera no highlight, or the light's strength is zero.  They are
+                                 counted in shadow_queries, queries and rays_api, as the reference counts them   */
 } t3d_stats;
 
 /* One trace-tree node as t3d_trace_pixel returns it (TraceTreeNode, T3DE.py:273-280). */

@@ -589,6 +589,11 @@ static void direct_light(Ctx* c, const Collision* ci, RGBd* color_out, double* i
         double vis = visibility(c, &br);
         double att = attenuation(vmag(vsub(pos, ci->point)));
         double intensity = ((diffuse * rough) + (spec * (1 - rough))) * strength * vis * att;
+        /* not part of the reference: how many shadow rays cannot change anything, the factor in front of the visibility
+           being zero -- or below 1e-6, where float32 may see a zero (a light in the plane of the surface it lights).
+           The reference and this oracle trace them all the same; the HIP library skips those whose factor is zero in
+           float32, and its count (t3d_stats.shadow_culled) must not exceed this one */
+        if ((diffuse * rough) + (spec * (1 - rough)) <= 1e-6 || strength == 0) c->st.shadow_culled++;
         total = rgb_add(total, rgb_mulk(color, 0.6));
         totalI += intensity;
     }

@@ -59,6 +59,8 @@
 #define T3D_MAX_LIGHTS 4096 /* every emissive face is a light (T3DR.py:789-816); 4 bytes per (node, light) */
 #define T3D_MAX_BOUNCES 14 /* heap index of the deepest node must fit 16 bits of the RNG key */
 #define T3D_SHARDS 64      /* queue shards per level; every launch holds a multiple of 64 waves */
+#define T3D_PAIRS 1024     /* (node, light) pairs per wave in the brute-force kernels' pair list: < 128 pending + <= 128 nodes x 7 lights */
+#define T3D_PAIR_LIGHTS 7  /* scenes with up to this many lights keep a list of the pairs whose light term can be non-zero */
 #define T3D_RING 256       /* nodes per wave in the brute-force kernels: < 128 pairs pending before a trace round, which adds <= 128 nodes */
 
 // ------------------------------------------------------------------------------------------------
@@ -423,6 +425,7 @@ __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0
 #define BVH_DONE 0x7fffffff
 struct BvhCount {
     uint32_t nodes, tris, spheres, deep;
+    uint32_t culled = 0;   // shadow rays answered without a traversal (shadow_dead)
 };
 
 // Traversal state of one ray (one lane).  bvh_begin sets it up, bvh_step advances it by one node record or one
@@ -646,9 +649,20 @@ __device__ __forceinline__ ShadowRay shadow_ray(const DevScene& sc, float4 ra, f
     s.strength = lt.strength;
     return s;
 }
+// The part of the light term that does not depend on what the shadow ray hits: diffuse and specular response of the
+// surface to the light's direction (T3DR.py:850-857, 880).  Where it is zero -- the surface faces away from the light
+// and shows no highlight to the camera -- the term is zero whatever the visibility, and the ray need not be traced.
+__device__ __forceinline__ float shadow_facing(const DevScene& sc, const ShadowRay& s) {
+    const V3 cam = mk(sc.cam.pos[0], sc.cam.pos[1], sc.cam.pos[2]);
+    const float ldn = dot(s.Ld, s.N);
+    const float diffuse = fmaxf(0.0f, ldn);
+    const V3 R = madd(s.Ld * -1.0f, s.N, 2.0f * ldn);
+    const float spec = (dot(normalize(R), normalize(cam - s.P)) < 0.96f) ? 0.0f : 1.0f;
+    return diffuse * s.rough + spec * (1.0f - s.rough);
+}
+__device__ __forceinline__ bool shadow_dead(const DevScene& sc, const ShadowRay& s) { return shadow_facing(sc, s) == 0.0f || s.strength == 0.0f; }
 __device__ __forceinline__ float shadow_intensity(const DevScene& sc, const DevSphere* __restrict__ spheres, const ShadowRay& s,
                                                   const Hit& h) {
-    const V3 cam = mk(sc.cam.pos[0], sc.cam.pos[1], sc.cam.pos[2]);
     float vis = 1.0f;
     if (h.prim >= 0) {
         if (h.prim < sc.n_tris) {
@@ -659,11 +673,7 @@ __device__ __forceinline__ float shadow_intensity(const DevScene& sc, const DevS
             if (!sp.is_light) vis = 1.0f - sc.shaders[sp.shader].refl;
         }
     }
-    const float ldn = dot(s.Ld, s.N);
-    const float diffuse = fmaxf(0.0f, ldn);
-    const V3 R = madd(s.Ld * -1.0f, s.N, 2.0f * ldn);
-    const float spec = (dot(normalize(R), normalize(cam - s.P)) < 0.96f) ? 0.0f : 1.0f;
-    return (diffuse * s.rough + spec * (1.0f - s.rough)) * s.strength * vis * attenuation(s.dist2);
+    return shadow_facing(sc, s) * s.strength * vis * attenuation(s.dist2);
 }
 
 // computeColor of a shaded node (T3DR.py:1054-1083) from its two child slots, its summed direct-light intensity and its
@@ -815,13 +825,21 @@ __device__ __forceinline__ Outcome hit_outcome(const DevScene& sc, const DevSphe
     return r;
 }
 
+// The wave's list of shadow rays still to trace, when the scene has few lights (PAIRS): (ring slot of the node, light),
+// node after node in ring order, only the pairs whose light term can be non-zero (shadow_dead).
+struct PairList {
+    unsigned short* ring;   // T3D_PAIRS entries in LDS: slot | light << 8
+    int tail;               // pairs appended so far (wave-uniform)
+    uint32_t culled;        // pairs answered without a ray, this lane
+};
+
 // Everything that follows the closest hit of ONE ray per lane (wave-collective: ballots and atomics):
 // classification, emitter / miss leaves, bounce and transmit rays, node record, queue appends, ring entry.
-template <bool LEVEL0, int RING>
+template <bool LEVEL0, int RING, bool PAIRS = false>
 __device__ __forceinline__ void process_ray(const DevScene& sc, const DevSphere* __restrict__ spheres, const RenderParams& rp,
                                             const WaveCtx& wc, const RayIn& in, const Hit& h, RayRec* __restrict__ rays_out,
                                             const NodePool& pool, Counters* cnt, const TraceOut& out, float4* ring_a,
-                                            float4* ring_b, int& ring_nodes) {
+                                            float4* ring_b, int& ring_nodes, PairList* pl = nullptr) {
     const Outcome oc = hit_outcome(sc, spheres, rp, in, h, LEVEL0, wc.level < rp.bounces, out);
     const V3 o = in.o, d = in.d, P = oc.P, N = oc.N, emit = oc.emit;
     const bool hit = oc.hit, emitter = oc.emitter, shaded = oc.shaded, want_t = oc.want_t, want_b = oc.want_b;
@@ -904,7 +922,37 @@ __device__ __forceinline__ void process_ray(const DevScene& sc, const DevSphere*
             rays_out[wc.shard * wc.shard_cap + bloc] = r;
         } else { cnt->overflow = 1; rp.sticky[0] = 1; }
     }
-    if constexpr (RING > 0) {
+    if constexpr (RING > 0 && PAIRS) {
+        // Which lights can add anything at this node?  Only those pairs are listed, node after node in lane order, and only
+        // nodes with such a pair enter the ring; the others get their zero here.
+        const float4 ra = make_float4(P.x, P.y, P.z, rough), rb = make_float4(N.x, N.y, N.z, 0.0f);
+        uint32_t live = 0;
+        int before = 0, total = 0;
+        for (int l = 0; l < wc.L; ++l) {
+            const bool lv = shaded && !shadow_dead(sc, shadow_ray(sc, ra, rb, l));
+            const unsigned long long m = __ballot(lv);
+            before += __popcll(m & wc.lt_mask);
+            total += __popcll(m);
+            live |= (uint32_t)lv << l;
+            if (shaded && !lv) {
+                if (stored) pool.li[(wc.node_base + (size_t)node) * wc.L + l] = 0.0f;
+                pl->culled++;
+            }
+        }
+        const unsigned long long m_r = __ballot(live != 0);
+        if (live) {
+            const int slot = (ring_nodes + __popcll(m_r & wc.lt_mask)) % RING;
+            ring_a[slot] = ra;
+            ring_b[slot] = make_float4(N.x, N.y, N.z, __int_as_float(stored ? node : 0));
+            int pos = pl->tail + before;
+            for (uint32_t bits = live; bits; bits &= bits - 1) {
+                pl->ring[pos % T3D_PAIRS] = (unsigned short)(slot | ((31 - __clz(bits & (0u - bits))) << 8));
+                ++pos;
+            }
+        }
+        ring_nodes += __popcll(m_r);
+        pl->tail += total;
+    } else if constexpr (RING > 0) {
         // shaded nodes enter the wave's ring in lane order
         if (shaded && wc.L > 0) {
             const int slot = (ring_nodes + nrank) % RING;
@@ -982,13 +1030,14 @@ __device__ __forceinline__ void load_ray(const DevScene& sc, const RenderParams&
 // 64-byte line, own slice of the arrays) with wave64 ballot + prefix-popcount compaction and ONE atomic
 // per counter per 64 rays.
 // ------------------------------------------------------------------------------------------------
-template <bool LEVEL0, int WAVES>
+template <bool LEVEL0, int WAVES, bool PAIRS>
 __global__ __launch_bounds__(64 * WAVES, 4) void k_level(DevScene sc, GEO_PARAMS, RenderParams rp, int level,
                                                       const RayRec* __restrict__ rays_in, RayRec* __restrict__ rays_out,
                                                       NodePool pool, Counters* cnt, TraceOut out) {
     constexpr int RING = T3D_RING;
     __shared__ float4 ring_a_all[WAVES][RING];  // P.xyz, roughness
     __shared__ float4 ring_b_all[WAVES][RING];  // unit normal, int bits: node index within the level
+    __shared__ unsigned short pair_ring_all[PAIRS ? WAVES : 1][PAIRS ? T3D_PAIRS : 1];
     WaveCtx wc;
     wc.lane = threadIdx.x & 63; wc.wid = threadIdx.x >> 6;
     wc.lt_mask = (1ull << wc.lane) - 1ull;
@@ -1018,21 +1067,30 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_level(DevScene sc, GEO_PARAMS
     int ring_nodes = 0;  // nodes appended to the ring so far      (wave-uniform)
     int items_done = 0;  // (node, light) pairs already traced     (wave-uniform)
     const float inv_L = 1.0f / (float)(L > 0 ? L : 1);
+    PairList pl{PAIRS ? pair_ring_all[wc.wid] : nullptr, 0, 0u};
     for (;;) {
-        const int pending = ring_nodes * L - items_done;
+        const int n_items = PAIRS ? pl.tail : ring_nodes * L;
+        const int pending = n_items - items_done;
         const bool more = (long long)chunk * cs < n_in;
         // nodes whose pairs are all done leave the ring: its 256 entries always hold 127 pending + 128 new nodes
         if (pending >= 128 || (!more && pending > 0)) {
             // ---------------- shadow round: pairs items_done + lane and items_done + 64 + lane ----------------
             const int item0 = items_done + wc.lane, item1 = item0 + 64;
-            const bool run0 = item0 < ring_nodes * L, run1 = item1 < ring_nodes * L;
-            // item = node * L + light.  items_done is wave-uniform, so its quotient and remainder by L are scalar
-            // work; per lane only a small offset (< L + 128) is divided, exactly, in float.
-            const int nd_base = __builtin_amdgcn_readfirstlane(items_done / L), l_base = __builtin_amdgcn_readfirstlane(items_done % L);
-            const int x0 = l_base + (run0 ? wc.lane : 0), x1 = l_base + (run1 ? wc.lane + 64 : 0);
-            const int q0 = (int)(((float)x0 + 0.5f) * inv_L), q1 = (int)(((float)x1 + 0.5f) * inv_L);
-            const int nd0 = nd_base + q0, nd1 = nd_base + q1;
-            const int l0 = x0 - q0 * L, l1 = x1 - q1 * L;
+            const bool run0 = item0 < n_items, run1 = item1 < n_items;
+            int nd0, nd1, l0, l1;
+            if constexpr (PAIRS) {
+                // a lane without a pair of its own repeats the round's first one and stores nothing
+                const int e0 = pl.ring[(run0 ? item0 : items_done) % T3D_PAIRS], e1 = pl.ring[(run1 ? item1 : items_done) % T3D_PAIRS];
+                nd0 = e0 & 255; l0 = e0 >> 8; nd1 = e1 & 255; l1 = e1 >> 8;
+            } else {
+                // item = node * L + light.  items_done is wave-uniform, so its quotient and remainder by L are scalar
+                // work; per lane only a small offset (< L + 128) is divided, exactly, in float.
+                const int nd_base = __builtin_amdgcn_readfirstlane(items_done / L), l_base = __builtin_amdgcn_readfirstlane(items_done % L);
+                const int x0 = l_base + (run0 ? wc.lane : 0), x1 = l_base + (run1 ? wc.lane + 64 : 0);
+                const int q0 = (int)(((float)x0 + 0.5f) * inv_L), q1 = (int)(((float)x1 + 0.5f) * inv_L);
+                nd0 = nd_base + q0; nd1 = nd_base + q1;
+                l0 = x0 - q0 * L; l1 = x1 - q1 * L;
+            }
             const float4 rb0 = ring_b[nd0 % RING], rb1 = ring_b[nd1 % RING];
             const ShadowRay s0 = shadow_ray(sc, ring_a[nd0 % RING], rb0, l0);
             const ShadowRay s1 = shadow_ray(sc, ring_a[nd1 % RING], rb1, l1);
@@ -1050,8 +1108,8 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_level(DevScene sc, GEO_PARAMS
             const bool lights = LEVEL0 ? (rp.lights != 0) : true;
             Hit h0, h1;  // back faces culled iff ray.ior == 1 (T3DR.py:961)
             closest_hit2<LEVEL0>(GEO_ARGS, sc.geo, in0.o, in0.d, in1.o, in1.d, lights, in0.ior == 1.0f, in1.ior == 1.0f, h0, h1);
-            process_ray<LEVEL0, RING>(sc, spheres, rp, wc, in0, h0, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes);
-            process_ray<LEVEL0, RING>(sc, spheres, rp, wc, in1, h1, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes);
+            process_ray<LEVEL0, RING, PAIRS>(sc, spheres, rp, wc, in0, h0, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes, &pl);
+            process_ray<LEVEL0, RING, PAIRS>(sc, spheres, rp, wc, in1, h1, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes, &pl);
             chunk += chunk_step;
             // the ring is private to this wave; LDS operations of one wave complete in order, the fences
             // only stop the compiler from moving the next round's reads above these writes
@@ -1061,6 +1119,12 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_level(DevScene sc, GEO_PARAMS
         } else {
             break;
         }
+    }
+    if constexpr (PAIRS) {
+        // shadow rays answered without being traced: wave sum, one atomic on the wave's own counter line
+        unsigned long long f = pl.culled;
+        for (int off = 32; off > 0; off >>= 1) f += __shfl_xor(f, off);
+        if (wc.lane == 0 && f) atomicAdd(&cnt->bvh_stat[wc.shard][4], f);
     }
 }
 
@@ -1100,15 +1164,16 @@ __device__ __forceinline__ void feed_refresh(RayFeed& f, PaddedCount* counter, i
 
 __device__ __forceinline__ void bvh_stats_flush(const BvhCount& bc, Counters* cnt, int lane, int shard) {
     // traversal statistics: wave sum, one atomic per counter on the wave's own counter line
-    unsigned long long a = bc.nodes, b = bc.tris, c = bc.spheres, e = bc.deep;
+    unsigned long long a = bc.nodes, b = bc.tris, c = bc.spheres, e = bc.deep, f = bc.culled;
     for (int off = 32; off > 0; off >>= 1) {
-        a += __shfl_xor(a, off); b += __shfl_xor(b, off); c += __shfl_xor(c, off); e += __shfl_xor(e, off);
+        a += __shfl_xor(a, off); b += __shfl_xor(b, off); c += __shfl_xor(c, off); e += __shfl_xor(e, off); f += __shfl_xor(f, off);
     }
     if (lane == 0) {
         atomicAdd(&cnt->bvh_stat[shard][0], a);
         atomicAdd(&cnt->bvh_stat[shard][1], b);
         atomicAdd(&cnt->bvh_stat[shard][2], c);
         if (e) atomicAdd(&cnt->bvh_stat[shard][3], e);
+        if (f) atomicAdd(&cnt->bvh_stat[shard][4], f);
     }
 }
 
@@ -1128,7 +1193,7 @@ __global__ __launch_bounds__(T3D_BLOCK, T3D_BVH_WAVES) void k_bvh_trace(DevScene
     int* lds = &lds_stack[threadIdx.x >> 6][0][lane];
     BvhLane st;
     int* deep = sc.bvh.spill + ((size_t)gw * T3D_BVH_DEEP_STACK) * 64 + lane;
-    BvhCount bc{0, 0, 0, 0};
+    BvhCount bc{0, 0, 0, 0, 0};
     bool have = false;     // a ray is in flight in this lane
     bool pending = false;  // a finished ray's result is still in st
     int mine = 0;          // where this lane's result goes
@@ -1207,7 +1272,7 @@ __global__ __launch_bounds__(T3D_BLOCK, T3D_BVH_WAVES) void k_bvh_shadow(DevScen
     int* lds = &lds_stack[threadIdx.x >> 6][0][lane];
     BvhLane st;
     int* deep = sc.bvh.spill + ((size_t)gw * T3D_BVH_DEEP_STACK) * 64 + lane;
-    BvhCount bc{0, 0, 0, 0};
+    BvhCount bc{0, 0, 0, 0, 0};
     bool have = false, pending = false;
     int my_node = 0, my_light = 0;
     RayFeed feed;
@@ -1231,8 +1296,14 @@ __global__ __launch_bounds__(T3D_BLOCK, T3D_BVH_WAVES) void k_bvh_shadow(DevScen
                 my_light = (int)(idx - (long long)nd * L);
                 my_node = shard * shard_cap + nd;
                 const ShadowRay s = shadow_ray(sc, src_a[my_node], src_b[my_node], my_light);
-                bvh_begin(st, s.start, s.Ld, true, false);
-                have = true;
+                if (shadow_dead(sc, s)) {
+                    // this light adds nothing at this node whatever lies between them: answered here, the lane stays idle
+                    pool.li[(node_base + (size_t)my_node) * L + my_light] = 0.0f;
+                    bc.culled++;
+                } else {
+                    bvh_begin(st, s.start, s.Ld, true, false);
+                    have = true;
+                }
             }
             feed.pos = feed.pos + n_idle < feed.end ? feed.pos + n_idle : feed.end;
         }
@@ -1314,7 +1385,7 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_closest(DevScene sc, GEO_PARAMS, 
         V3 d = normalize(mk(dirs[3 * j], dirs[3 * j + 1], dirs[3 * j + 2]));
         Hit h, h_dup;
         if (sc.bvh.nodes) {  // uniform over the launch
-            BvhCount bc{0, 0, 0, 0};
+            BvhCount bc{0, 0, 0, 0, 0};
             int overflow = 0;
             const int gw = blockIdx.x * T3D_WAVES + (threadIdx.x >> 6);
             bvh_closest(sc, spheres, o, d, active, lights != 0, back_cull != 0, h, bc, &overflow, &lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63],
@@ -1406,6 +1477,9 @@ struct t3d_ctx {
     // that a picked pixel neither frees the band buffers nor invalidates the launch graphs that hold their addresses
     Work work, single_work;
     hipStream_t shadow_stream = nullptr;             // k_bvh_shadow of level d runs beside the tracing of level d + 1
+    hipStream_t capture_stream = nullptr;            // launch graphs are recorded here, never on a caller's stream: other threads of
+                                                     // the process (a collective library's watchdog) may query events of that stream
+                                                     // at any moment, which HIP refuses while the stream records
     hipEvent_t ev_traced[T3D_MAX_BOUNCES + 2] = {};  // level d classified: its shadow rays may start
     hipEvent_t ev_shadowed[T3D_MAX_BOUNCES + 2] = {};  // shadow rays of level d done
     Counters* d_cnt = nullptr;            // counters of the current / most recent band: one of the pair
@@ -1492,6 +1566,7 @@ extern "C" int t3d_create(int device, t3d_ctx** out) {
     if ((e = hipSetDevice(device)) != hipSuccess) return fail(T3D_E_DEVICE, hipGetErrorString(e));
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail(T3D_E_DEVICE, hipGetErrorString(e));
     if ((e = hipStreamCreateWithFlags(&c->shadow_stream, hipStreamNonBlocking)) != hipSuccess) return fail(T3D_E_DEVICE, hipGetErrorString(e));
+    if ((e = hipStreamCreateWithFlags(&c->capture_stream, hipStreamNonBlocking)) != hipSuccess) return fail(T3D_E_DEVICE, hipGetErrorString(e));
     for (auto& ev : c->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(T3D_E_DEVICE, hipGetErrorString(e));
     for (auto& ev : c->ev_traced) if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return fail(T3D_E_DEVICE, hipGetErrorString(e));
     for (auto& ev : c->ev_shadowed) if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return fail(T3D_E_DEVICE, hipGetErrorString(e));
@@ -1552,6 +1627,7 @@ extern "C" void t3d_destroy(t3d_ctx* c) {
     for (auto& ev : c->ev_traced) if (ev) hipEventDestroy(ev);
     for (auto& ev : c->ev_shadowed) if (ev) hipEventDestroy(ev);
     if (c->shadow_stream) hipStreamDestroy(c->shadow_stream);
+    if (c->capture_stream) hipStreamDestroy(c->capture_stream);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1925,6 +2001,9 @@ static void fill_stats(t3d_ctx* c, t3d_stats* stats) {
     stats->queries += q;
     stats->trace_queries += rays;
     stats->shadow_queries += shadow;
+    uint64_t culled = 0;
+    for (int sh = 0; sh < T3D_SHARDS; ++sh) culled += c->h_cnt->bvh_stat[sh][4];
+    stats->shadow_culled += culled;
     if (c->use_bvh) {
         uint64_t nv = 0, tt = 0, stt = 0;
         for (int sh = 0; sh < T3D_SHARDS; ++sh) {
@@ -1935,8 +2014,8 @@ static void fill_stats(t3d_ctx* c, t3d_stats* stats) {
         stats->tri_tests += tt;
         stats->sphere_tests += stt;
     } else {
-        stats->tri_tests += q * (uint64_t)c->sc.n_tris;
-        stats->sphere_tests += q * (uint64_t)c->sc.n_spheres - (c->last_lights ? 0 : c->last_n0 * (uint64_t)c->n_light_objs);
+        stats->tri_tests += (q - culled) * (uint64_t)c->sc.n_tris;
+        stats->sphere_tests += (q - culled) * (uint64_t)c->sc.n_spheres - (c->last_lights ? 0 : c->last_n0 * (uint64_t)c->n_light_objs);
     }
     stats->nodes += nodes;  // shaded nodes only; emitter leaves are folded into their parents
     stats->launches += c->last_launches;
@@ -2037,6 +2116,7 @@ static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int nro
     static_assert(sizeof(RenderParams) + 12 * sizeof(void*) <= sizeof key, "graph key");
     const bool graphable = c->graphs_enabled && !events && !single && !c->use_bvh && !cancellable && !fixed_work;
     bool capturing = false;
+    hipStream_t ls = st;   // where the brute-force path's kernels are queued: the call's stream, or the recording stream
     t3d_ctx::FrameGraph* slot = nullptr;
     if (graphable) {
         memset(key, 0, sizeof key);
@@ -2051,7 +2131,7 @@ static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int nro
                 goto issued;
             }
         if (memcmp(c->graph_miss[0], key, sizeof key) == 0 || memcmp(c->graph_miss[1], key, sizeof key) == 0) {
-            if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess) capturing = true;
+            if (hipStreamBeginCapture(c->capture_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) { capturing = true; ls = c->capture_stream; }
             else { (void)hipGetLastError(); c->graphs_enabled = false; }
         } else {
             memcpy(c->graph_miss[c->graph_miss_next], key, sizeof key);
@@ -2097,19 +2177,18 @@ static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int nro
         } else {
             // waves of k_level never talk to each other: one wave per workgroup, so that a finished wave's slot is free at
             // once instead of when the slowest of four is done (1.5 % on the benchmark frame)
+            const bool pairs = c->sc.n_lights >= 1 && c->sc.n_lights <= T3D_PAIR_LIGHTS;
+#define T3D_LAUNCH_LEVEL(L0, W, P, GRID, BLOCK)                                                                                   \
+    hipLaunchKernelGGL((k_level<L0, W, P>), dim3(GRID), dim3(BLOCK), 0, ls, c->sc, planes, pfirst, uv, sph, rp, d, in, outq, w.pool, \
+                       c->d_cnt, out)
             if (!single) {
-                if (d == 0)
-                    hipLaunchKernelGGL((k_level<true, 1>), dim3(grid_n * T3D_WAVES), dim3(64), 0, st, c->sc, planes, pfirst, uv, sph, rp, d, in, outq,
-                                       w.pool, c->d_cnt, out);
-                else
-                    hipLaunchKernelGGL((k_level<false, 1>), dim3(grid_n * T3D_WAVES), dim3(64), 0, st, c->sc, planes, pfirst, uv, sph, rp, d, in, outq,
-                                       w.pool, c->d_cnt, out);
-            } else if (d == 0)
-                hipLaunchKernelGGL((k_level<true, T3D_WAVES>), dim3(grid_n), dim3(T3D_BLOCK), 0, st, c->sc, planes, pfirst, uv, sph, rp, d, in, outq,
-                                   w.pool, c->d_cnt, out);
-            else
-                hipLaunchKernelGGL((k_level<false, T3D_WAVES>), dim3(grid_n), dim3(T3D_BLOCK), 0, st, c->sc, planes, pfirst, uv, sph, rp, d, in, outq,
-                                   w.pool, c->d_cnt, out);
+                if (d == 0) { if (pairs) T3D_LAUNCH_LEVEL(true, 1, true, grid_n * T3D_WAVES, 64); else T3D_LAUNCH_LEVEL(true, 1, false, grid_n * T3D_WAVES, 64); }
+                else        { if (pairs) T3D_LAUNCH_LEVEL(false, 1, true, grid_n * T3D_WAVES, 64); else T3D_LAUNCH_LEVEL(false, 1, false, grid_n * T3D_WAVES, 64); }
+            } else {
+                if (d == 0) { if (pairs) T3D_LAUNCH_LEVEL(true, T3D_WAVES, true, grid_n, T3D_BLOCK); else T3D_LAUNCH_LEVEL(true, T3D_WAVES, false, grid_n, T3D_BLOCK); }
+                else        { if (pairs) T3D_LAUNCH_LEVEL(false, T3D_WAVES, true, grid_n, T3D_BLOCK); else T3D_LAUNCH_LEVEL(false, T3D_WAVES, false, grid_n, T3D_BLOCK); }
+            }
+#undef T3D_LAUNCH_LEVEL
             launches += 1;
         }
         if (c->timing) HIPCHK(c, tick());  // ev[1 + d]: level d traced
@@ -2128,12 +2207,12 @@ static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int nro
     if (overlap && c->sc.n_lights > 0)   // the resolve reads every level's light intensities
         for (int d = levels >= 2 ? levels - 2 : 0; d < levels; ++d) HIPCHK(c, hipStreamWaitEvent(st, c->ev_shadowed[d], 0));
     for (int d = levels - 1; d >= 0; --d) {
-        hipLaunchKernelGGL(k_resolve, dim3(single ? 1 : trace_blocks_for(cap_used)), dim3(T3D_BLOCK), 0, st, c->sc, rp, d, w.pool, c->d_cnt,
+        hipLaunchKernelGGL(k_resolve, dim3(single ? 1 : trace_blocks_for(cap_used)), dim3(T3D_BLOCK), 0, ls, c->sc, rp, d, w.pool, c->d_cnt,
                            w.sample_color, d_dbg, dbg_cap, out.bgr, out.radiance, (uint4*)next_cnt, (int)(sizeof(Counters) / sizeof(uint4)));
         launches++;
     }
     if (!single && !direct) {
-        hipLaunchKernelGGL(k_finish, dim3(blocks_for((size_t)nrows * o->width)), dim3(T3D_BLOCK), 0, st, rp, w.sample_color, d_bgr, d_rad);
+        hipLaunchKernelGGL(k_finish, dim3(blocks_for((size_t)nrows * o->width)), dim3(T3D_BLOCK), 0, ls, rp, w.sample_color, d_bgr, d_rad);
         launches++;
     }
     if (capturing) {
@@ -2141,7 +2220,7 @@ static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int nro
         slot = &c->graphs[c->graph_next];
         c->graph_next = (c->graph_next + 1) % 4;
         if (slot->valid) { hipGraphExecDestroy(slot->exec); hipGraphDestroy(slot->graph); slot->valid = false; }
-        hipError_t e = hipStreamEndCapture(st, &slot->graph);
+        hipError_t e = hipStreamEndCapture(c->capture_stream, &slot->graph);
         if (e == hipSuccess) {
             e = hipGraphInstantiate(&slot->exec, slot->graph, nullptr, nullptr, 0);
             if (e != hipSuccess) hipGraphDestroy(slot->graph);
@@ -2247,7 +2326,7 @@ extern "C" int t3d_render_rows_device(t3d_ctx* c, const t3d_opts* o, int row0, i
                     stats->level_rays[k] += band_stats.level_rays[k]; stats->level_nodes[k] += band_stats.level_nodes[k];
                     stats->level_ms[k] += band_stats.level_ms[k];
                 }
-                stats->bvh_deep_pushes += band_stats.bvh_deep_pushes;
+                stats->bvh_deep_pushes += band_stats.bvh_deep_pushes; stats->shadow_culled += band_stats.shadow_culled;
             }
             break;
         }
@@ -2341,7 +2420,7 @@ extern "C" int t3d_render_rows_device_static(t3d_ctx* c, const t3d_opts* o, int 
                     stats->level_rays[k] += band_stats.level_rays[k]; stats->level_nodes[k] += band_stats.level_nodes[k];
                     stats->level_ms[k] += band_stats.level_ms[k];
                 }
-                stats->bvh_deep_pushes += band_stats.bvh_deep_pushes;
+                stats->bvh_deep_pushes += band_stats.bvh_deep_pushes; stats->shadow_culled += band_stats.shadow_culled;
             }
             break;
         }
@@ -2532,7 +2611,7 @@ extern "C" int t3d_render_frame_multi(t3d_ctx* const* ctxs, int n, const t3d_opt
                 stats->level_rays[q] += sts[k].level_rays[q]; stats->level_nodes[q] += sts[k].level_nodes[q];
                 stats->level_ms[q] = fmax(stats->level_ms[q], sts[k].level_ms[q]);
             }
-            stats->bvh_deep_pushes += sts[k].bvh_deep_pushes;
+            stats->bvh_deep_pushes += sts[k].bvh_deep_pushes; stats->shadow_culled += sts[k].shadow_culled;
         }
     }
     return T3D_OK;

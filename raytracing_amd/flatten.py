@@ -55,7 +55,7 @@ class Stats(C.Structure):
                                           "sphere_tests", "aabb_tests", "nodes", "launches", "n_k_level")] + \
                [(n, C.c_double) for n in ("ms_device", "ms_k_level", "ms_resolve")] + \
                [("level_rays", C.c_uint64 * 16), ("level_nodes", C.c_uint64 * 16), ("level_ms", C.c_double * 16),
-                ("bvh_deep_pushes", C.c_uint64)]
+                ("bvh_deep_pushes", C.c_uint64), ("shadow_culled", C.c_uint64)]
 
     def as_dict(self):
         return {name: (list(getattr(self, name)) if name.startswith("level_") else getattr(self, name))

@@ -271,7 +271,8 @@ def test_bench_with_two_ranks_rehearsed_on_one_gpu():
     d = _run_bench_ranks(2, ["--dist-backend", "gloo"])
     assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["scaling"] == "strong" and d["steps"] == 3
     assert d["config"]["partition"] == "interleaved rows x2" and "gloo" in d["config"]["collective"]
-    assert d["config"]["queries_per_frame"] == 17874992          # both halves of the frame, summed over the ranks
+    assert d["config"]["reference_queries_per_frame"] == 17874992          # both halves of the frame, summed over the ranks
+    assert d["config"]["queries_per_frame"] + d["config"]["shadow_rays_answered_untraced_per_frame"] == 17874992
     assert d["value"] > 0 and "cpu_baseline" not in d          # the CPU baseline is a one-rank field
 
 
@@ -281,4 +282,4 @@ def test_bench_with_two_ranks_over_rccl():
     if _native.device_count() < 2:
         pytest.skip("needs two GPUs")
     d = _run_bench_ranks(2, [])
-    assert d["n_gpus"] == 2 and d["config"]["collective"] == "RCCL gather" and d["config"]["queries_per_frame"] == 17874992
+    assert d["n_gpus"] == 2 and d["config"]["collective"] == "RCCL gather" and d["config"]["reference_queries_per_frame"] == 17874992
