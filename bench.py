@@ -239,6 +239,9 @@ def main():
                       ("Cornell 1080p 4 bounces" if args.workload == "cornell_1080p_b4" else args.workload),
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            # the same frames per second in the reference's count of rays (it traces, and counts, the shadow rays that this
+            # library answers without tracing): the figure to set against cpu_baseline, whose oracle traces them all
+            "value_in_reference_queries": round(totals["queries"] * args.steps / elapsed / 1e6, 2),
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "ranks": world, "collective": ("gloo gather through host memory (rehearsal)" if gloo else
                                                                                ("RCCL gather" if world > 1 else "none")),

@@ -60,6 +60,7 @@
 #define T3D_MAX_BOUNCES 14 /* heap index of the deepest node must fit 16 bits of the RNG key */
 #define T3D_SHARDS 64      /* queue shards per level; every launch holds a multiple of 64 waves */
 #define T3D_PAIRS 1024     /* (node, light) pairs per wave in the brute-force kernels' pair list: < 128 pending + <= 128 nodes x 7 lights */
+#define T3D_LIVE_SHIFT 20  /* node records of such scenes: shader index in bits 0..19, the listed lights in bits 20..26, the side in bit 30 */
 #define T3D_PAIR_LIGHTS 7  /* scenes with up to this many lights keep a list of the pairs whose light term can be non-zero */
 #define T3D_RING 256       /* nodes per wave in the brute-force kernels: < 128 pairs pending before a trace round, which adds <= 128 nodes */
 
@@ -142,6 +143,7 @@ struct RenderParams {
     int tiled;              // level 0 walks the band in 16 x 8 pixel tiles (width % 16 == 0, rows % 8 == 0)
     float ray_o[3], ray_d[3], ray_ior;  // single == 2: the initial ray (unit direction) ...
     int ray_obj;                        // ... and the object it travels inside (-1 none)
+    int live_masks;  // the node records list the lights whose shadow rays were traced (brute-force path, few lights)
     int shard_bits;  // log2 of the number of queue shards in use: 6 for image bands, 0 for the tree of a single ray
     int* sticky;     // two host-visible words (pinned memory): [0] set when a queue or node array overflows, [1] when a
                      // traversal stack does; see t3d_ctx
@@ -894,11 +896,26 @@ __device__ __forceinline__ void process_ray(const DevScene& sc, const DevSphere*
     const int node = wc.shard * wc.shard_cap + nloc;                  // index within the level
     const bool stored = shaded && nloc < wc.shard_cap;
     if (shaded && !stored) { cnt->overflow = 1; rp.sticky[0] = 1; }
+    // Few lights (PAIRS): which of them can add anything at this node?  Only those (node, light) pairs are listed for the
+    // shadow rounds, node after node in lane order; the node record says which, so the others' intensities are never read.
+    uint32_t live = 0;
+    int pairs_before = 0, pairs_total = 0;
+    if constexpr (RING > 0 && PAIRS) {
+        const float4 ra = make_float4(P.x, P.y, P.z, rough), rb = make_float4(N.x, N.y, N.z, 0.0f);
+        for (int l = 0; l < wc.L; ++l) {
+            const bool lv = shaded && !shadow_dead(sc, shadow_ray(sc, ra, rb, l));
+            const unsigned long long m = __ballot(lv);
+            pairs_before += __popcll(m & wc.lt_mask);
+            pairs_total += __popcll(m);
+            live |= (uint32_t)lv << l;
+        }
+    }
     if (stored) {
         const float k = 2.0f / 255.0f;  // absent children count as ambient * 2/255 (T3DR.py:1054-1055)
         const size_t g = wc.node_base + (size_t)node;
         pool.c[g] = make_float4(rp.ambient[0] * k, rp.ambient[1] * k, rp.ambient[2] * k, att_parent);
-        pool.d[g] = make_float4(rp.ambient[0] * k, rp.ambient[1] * k, rp.ambient[2] * k, __int_as_float(shader | (in.side << 30)));
+        pool.d[g] = make_float4(rp.ambient[0] * k, rp.ambient[1] * k, rp.ambient[2] * k,
+                                __int_as_float(shader | (int)(live << T3D_LIVE_SHIFT) | (in.side << 30)));
         pool.parent[g] = in.parent;
         if (rp.want_debug) pool.dbg[g] = dbg_idx;
     }
@@ -923,35 +940,19 @@ __device__ __forceinline__ void process_ray(const DevScene& sc, const DevSphere*
         } else { cnt->overflow = 1; rp.sticky[0] = 1; }
     }
     if constexpr (RING > 0 && PAIRS) {
-        // Which lights can add anything at this node?  Only those pairs are listed, node after node in lane order, and only
-        // nodes with such a pair enter the ring; the others get their zero here.
-        const float4 ra = make_float4(P.x, P.y, P.z, rough), rb = make_float4(N.x, N.y, N.z, 0.0f);
-        uint32_t live = 0;
-        int before = 0, total = 0;
-        for (int l = 0; l < wc.L; ++l) {
-            const bool lv = shaded && !shadow_dead(sc, shadow_ray(sc, ra, rb, l));
-            const unsigned long long m = __ballot(lv);
-            before += __popcll(m & wc.lt_mask);
-            total += __popcll(m);
-            live |= (uint32_t)lv << l;
-            if (shaded && !lv) {
-                if (stored) pool.li[(wc.node_base + (size_t)node) * wc.L + l] = 0.0f;
-                pl->culled++;
-            }
-        }
+        // only nodes with a listed pair enter the ring
         const unsigned long long m_r = __ballot(live != 0);
         if (live) {
             const int slot = (ring_nodes + __popcll(m_r & wc.lt_mask)) % RING;
-            ring_a[slot] = ra;
+            ring_a[slot] = make_float4(P.x, P.y, P.z, rough);
             ring_b[slot] = make_float4(N.x, N.y, N.z, __int_as_float(stored ? node : 0));
-            int pos = pl->tail + before;
-            for (uint32_t bits = live; bits; bits &= bits - 1) {
-                pl->ring[pos % T3D_PAIRS] = (unsigned short)(slot | ((31 - __clz(bits & (0u - bits))) << 8));
-                ++pos;
-            }
+            const int pos = pl->tail + pairs_before;
+            for (int l = 0; l < wc.L; ++l)
+                if ((live >> l) & 1u) pl->ring[(pos + __popc(live & ((1u << l) - 1u))) % T3D_PAIRS] = (unsigned short)(slot | (l << 8));
         }
+        if (shaded) pl->culled += (uint32_t)(wc.L - __popc(live));
         ring_nodes += __popcll(m_r);
-        pl->tail += total;
+        pl->tail += pairs_total;
     } else if constexpr (RING > 0) {
         // shaded nodes enter the wave's ring in lane order
         if (shaded && wc.L > 0) {
@@ -1332,11 +1333,15 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_resolve(DevScene sc, RenderParams
         const size_t g = node_base + (size_t)shard * shard_cap + (size_t)k;
         const float4 c = pool.c[g], d = pool.d[g];
         const int meta = __float_as_int(d.w);
-        const int shader = meta & 0x3FFFFFFF, side = (meta >> 30) & 1;
+        // a scene with few lights on the brute-force path: the record lists the lights that can add anything at the node,
+        // the shadow rays of the others were never traced and their intensities (zero) never written
+        const int shader = meta & (rp.live_masks ? (1 << T3D_LIVE_SHIFT) - 1 : 0x3FFFFFFF), side = (meta >> 30) & 1;
+        const uint32_t live = rp.live_masks ? (uint32_t)(meta >> T3D_LIVE_SHIFT) & ((1u << T3D_PAIR_LIGHTS) - 1u) : 0xFFFFFFFFu;
         const int parent = pool.parent[g];
         DevShader sh = sc.shaders[shader];
         float I = 0.0f;
-        for (int l = 0; l < sc.n_lights; ++l) I += pool.li[g * sc.n_lights + l];  // light order, T3DR.py:894
+        for (int l = 0; l < sc.n_lights; ++l)   // light order, T3DR.py:894
+            if (!rp.live_masks || ((live >> l) & 1u)) I += pool.li[g * sc.n_lights + l];
         float res[3];
         node_color(sc, rp, sh, c, d, I, res);
         if (rp.want_debug) {
@@ -2057,6 +2062,9 @@ static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int nro
     rp.tiled = !single && o->width % 16 == 0 && nrows % 8 == 0;
     rp.full_rounds = c->full_rounds && !single;
     rp.shard_bits = shard_bits;
+    // few lights on the brute-force path: k_level lists the (node, light) pairs worth a shadow ray (PAIRS)
+    const bool pairs = !c->use_bvh && c->sc.n_lights >= 1 && c->sc.n_lights <= T3D_PAIR_LIGHTS && c->sc.n_shaders < (1 << T3D_LIVE_SHIFT);
+    rp.live_masks = pairs;
     rp.sticky = c->h_sticky;
     if (single) {
         rp.single = single->single; rp.px0 = single->px0; rp.py0 = single->py0; rp.sample0 = single->sample0; rp.want_debug = 1;
@@ -2177,7 +2185,6 @@ static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int nro
         } else {
             // waves of k_level never talk to each other: one wave per workgroup, so that a finished wave's slot is free at
             // once instead of when the slowest of four is done (1.5 % on the benchmark frame)
-            const bool pairs = c->sc.n_lights >= 1 && c->sc.n_lights <= T3D_PAIR_LIGHTS;
 #define T3D_LAUNCH_LEVEL(L0, W, P, GRID, BLOCK)                                                                                   \
     hipLaunchKernelGGL((k_level<L0, W, P>), dim3(GRID), dim3(BLOCK), 0, ls, c->sc, planes, pfirst, uv, sph, rp, d, in, outq, w.pool, \
                        c->d_cnt, out)
