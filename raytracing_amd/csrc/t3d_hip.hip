@@ -2214,7 +2214,10 @@ static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int nro
     if (overlap && c->sc.n_lights > 0)   // the resolve reads every level's light intensities
         for (int d = levels >= 2 ? levels - 2 : 0; d < levels; ++d) HIPCHK(c, hipStreamWaitEvent(st, c->ev_shadowed[d], 0));
     for (int d = levels - 1; d >= 0; --d) {
-        hipLaunchKernelGGL(k_resolve, dim3(single ? 1 : trace_blocks_for(cap_used)), dim3(T3D_BLOCK), 0, ls, c->sc, rp, d, w.pool, c->d_cnt,
+        // eight workgroups per CU at most: a grid twice that size is no faster for these short, memory-bound launches
+        int rgrid = trace_blocks_for(cap_used);
+        { int mx = c->n_sm * 8; mx = (mx + (int)grid_unit - 1) / (int)grid_unit * (int)grid_unit; if (rgrid > mx) rgrid = mx; }
+        hipLaunchKernelGGL(k_resolve, dim3(single ? 1 : rgrid), dim3(T3D_BLOCK), 0, ls, c->sc, rp, d, w.pool, c->d_cnt,
                            w.sample_color, d_dbg, dbg_cap, out.bgr, out.radiance, (uint4*)next_cnt, (int)(sizeof(Counters) / sizeof(uint4)));
         launches++;
     }
