@@ -8,7 +8,9 @@
 
 One step = one complete frame: every rank traces its interleaved image rows through libt3d_hip.so
 (scene resident in HBM, output tile in HBM), then the tiles are gathered on rank 0 (RCCL).  A "ray" is
-one closest-hit query (primary + bounce + transmit + shadow).  Consecutive steps are independent frames, and
+one closest-hit query that is traced (primary + bounce + transmit + shadow); shadow rays whose light term is zero
+whatever they hit are answered without a ray and not counted (value_in_reference_queries counts them, as the
+reference does).  Consecutive steps are independent frames, and
 several are in flight at a time (--frames-in-flight, config.frames_in_flight), each a chain of its own: a
 context, a stream, a tile buffer; trace, then gather, on that stream.  Prints ONE JSON line on rank 0.
 
@@ -142,7 +144,7 @@ def main():
     lbvh_scene = args.accel == "lbvh" or (args.accel == "auto" and flat.n_tris + flat.n_spheres > 256)
     # one rank's share of a frame is a chain of small launches: more of them in flight, and full rounds (no slot of a
     # round wasted; the other chains hide the latency the adaptive cut is there to shorten)
-    F = args.frames_in_flight if args.frames_in_flight > 0 else (1 if lbvh_scene else (2 if world == 1 else (3 if world == 2 else 4)))
+    F = args.frames_in_flight if args.frames_in_flight > 0 else (1 if lbvh_scene else (3 if world <= 2 else 4))
     H, W = options["height"], options["width"]
     tile = partition_rows(H, world, rank, args.partition)
     ctxs, outs, streams = [], [], []

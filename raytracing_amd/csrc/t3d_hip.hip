@@ -357,21 +357,18 @@ __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0
     const uint32_t INF_BITS = 0x7f800000u;
     const f2 ox = {o0.x, o1.x}, oy = {o0.y, o1.y}, oz = {o0.z, o1.z};
     const f2 dx = {d0.x, d1.x}, dy = {d0.y, d1.y}, dz = {d0.z, d1.z};
-    if constexpr (BOX_FIRST) {
-        if (!__any((int)ray_meets_scene_box(geo, o0, d0) | (int)ray_meets_scene_box(geo, o1, d1))) {   // wave-uniform
-            out0.t = out1.t = __builtin_inff(); out0.prim = out1.prim = -1; out0.back = out1.back = 0;
-            return;
-        }
-    }
+    bool any_inside = true;   // wave-uniform
+    if constexpr (BOX_FIRST) any_inside = __any((int)ray_meets_scene_box(geo, o0, d0) | (int)ray_meets_scene_box(geo, o1, d1));
     const f2 cull = {back_cull0 ? 0.0f : __builtin_inff(), back_cull1 ? 0.0f : __builtin_inff()};
     const f2 big = splat(0x1p126f);
     uint32_t best0 = INF_BITS, best1 = INF_BITS;
     float A0 = 0.0f, A1 = 0.0f;
     int bg0 = 0, bg1 = 0;
+    int prim0 = -1, prim1 = -1, back0 = 0, back1 = 0;
+    if (any_inside) {
     plane_groups<0, NO_CULL>(planes, plane_first, tri_uv, 0, geo.axis_end[0], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1);
     plane_groups<1, NO_CULL>(planes, plane_first, tri_uv, geo.axis_end[0], geo.axis_end[1], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1);
     plane_groups<2, NO_CULL>(planes, plane_first, tri_uv, geo.axis_end[1], geo.axis_end[2], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1);
-    int prim0 = -1, prim1 = -1, back0 = 0, back1 = 0;
     if (best0 < INF_BITS) prim0 = first_hit_of_group(plane_first, bg0, A0);
     if (best1 < INF_BITS) prim1 = first_hit_of_group(plane_first, bg1, A1);
     // Spheres and lights.  getSphereCollision (T3DR.py:572-598), Ray.getTSphere (T3DE.py:145-163).
@@ -403,6 +400,7 @@ __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0
             const bool closer = tt < best1;
             best1 = closer ? tt : best1; prim1 = closer ? n_tris + s : prim1; back1 = closer ? (front ? 0 : 1) : back1;
         }
+    }
     }
     out0.t = __uint_as_float(best0); out0.prim = prim0; out0.back = back0;
     out1.t = __uint_as_float(best1); out1.prim = prim1; out1.back = back1;
@@ -726,8 +724,12 @@ struct Outcome {
 
 // level0: the ray is a primary ray (its leaf colours go to the pixel, its hit to the primary-id outputs);
 // may_spawn: the ray's level is below options['bounces'] (T3DR.py:976-977)
+// ONE: the launch may be the tree of a single ray (t3d_trace_pixel / t3d_trace_ray); kernels that only ever trace image
+// bands say so, and the parameters of that mode are not kept in registers
+template <bool ONE = true>
 __device__ __forceinline__ Outcome hit_outcome(const DevScene& sc, const DevSphere* __restrict__ spheres, const RenderParams& rp,
                                                const RayIn& in, const Hit& h, bool level0, bool may_spawn, const TraceOut& out) {
+    const int single = ONE ? rp.single : 0;
     Outcome r;
     const V3 o = in.o, d = in.d;
     r.hit = in.active && h.prim >= 0;
@@ -768,8 +770,8 @@ __device__ __forceinline__ Outcome hit_outcome(const DevScene& sc, const DevSphe
         }
     }
     if (level0 && in.active) {
-        if (in.smp == 0 || rp.single) {
-            int pix = rp.single ? 0 : in.i / rp.samples;
+        if (in.smp == 0 || single) {
+            int pix = single ? 0 : in.i / rp.samples;
             if (out.primary) { out.primary[2 * pix] = r.obj; out.primary[2 * pix + 1] = r.face; }
             if (out.primary_t) out.primary_t[pix] = r.hit ? h.t : __builtin_nanf("");
         }
@@ -837,12 +839,13 @@ struct PairList {
 
 // Everything that follows the closest hit of ONE ray per lane (wave-collective: ballots and atomics):
 // classification, emitter / miss leaves, bounce and transmit rays, node record, queue appends, ring entry.
-template <bool LEVEL0, int RING, bool PAIRS = false>
+template <bool LEVEL0, int RING, bool PAIRS = false, bool ONE = true>
 __device__ __forceinline__ void process_ray(const DevScene& sc, const DevSphere* __restrict__ spheres, const RenderParams& rp,
                                             const WaveCtx& wc, const RayIn& in, const Hit& h, RayRec* __restrict__ rays_out,
                                             const NodePool& pool, Counters* cnt, const TraceOut& out, float4* ring_a,
                                             float4* ring_b, int& ring_nodes, PairList* pl = nullptr) {
-    const Outcome oc = hit_outcome(sc, spheres, rp, in, h, LEVEL0, wc.level < rp.bounces, out);
+    const Outcome oc = hit_outcome<ONE>(sc, spheres, rp, in, h, LEVEL0, wc.level < rp.bounces, out);
+    const bool want_debug = ONE && rp.want_debug;
     const V3 o = in.o, d = in.d, P = oc.P, N = oc.N, emit = oc.emit;
     const bool hit = oc.hit, emitter = oc.emitter, shaded = oc.shaded, want_t = oc.want_t, want_b = oc.want_b;
     const int shader = oc.shader;
@@ -853,7 +856,7 @@ __device__ __forceinline__ void process_ray(const DevScene& sc, const DevSphere*
 
     // ---- debug record (single-pixel mode) ----------------------------------------------
     int dbg_idx = -1;
-    if (rp.want_debug && hit) {
+    if (want_debug && hit) {
         dbg_idx = atomicAdd(&cnt->n_dbg, 1);
         if (dbg_idx < out.dbg_cap) {
             t3d_node& nd = out.dbg[dbg_idx];
@@ -917,7 +920,7 @@ __device__ __forceinline__ void process_ray(const DevScene& sc, const DevSphere*
         pool.d[g] = make_float4(rp.ambient[0] * k, rp.ambient[1] * k, rp.ambient[2] * k,
                                 __int_as_float(shader | (int)(live << T3D_LIVE_SHIFT) | (in.side << 30)));
         pool.parent[g] = in.parent;
-        if (rp.want_debug) pool.dbg[g] = dbg_idx;
+        if (want_debug) pool.dbg[g] = dbg_idx;
     }
     if (want_t && stored) {
         if (tloc < wc.shard_cap) {
@@ -970,9 +973,10 @@ __device__ __forceinline__ void process_ray(const DevScene& sc, const DevSphere*
     }
 }
 
-template <bool LEVEL0>
+template <bool LEVEL0, bool ONE = true>
 __device__ __forceinline__ void load_ray(const DevScene& sc, const RenderParams& rp, const RayRec* __restrict__ rays_in,
                                          int idx, int n_in, int queue_base, RayIn& in) {
+    const int single = ONE ? rp.single : 0;
     in.active = idx < n_in;
     in.i = LEVEL0 ? idx : queue_base + idx;
     in.o = mk(0, 0, 0); in.d = mk(0, 0, 1); in.pstart = mk(0, 0, 0);
@@ -994,10 +998,10 @@ __device__ __forceinline__ void load_ray(const DevScene& sc, const RenderParams&
             int ly = pix / rp.width;
             in.px = pix - ly * rp.width;
             in.py = rp.row0 + ly * rp.row_stride;
-            if (rp.single) { in.px = rp.px0; in.py = rp.py0; in.smp = rp.sample0; }
+            if (single) { in.px = rp.px0; in.py = rp.py0; in.smp = rp.sample0; }
             in.pixel_hash = keyed_pixel_hash(rp.seed, (uint32_t)in.px, (uint32_t)in.py);
             in.heap = (((uint32_t)in.smp & 0xFFFFu) << 16) | 1u;
-            if (rp.single == 2) {
+            if (single == 2) {
                 in.o = mk(rp.ray_o[0], rp.ray_o[1], rp.ray_o[2]); in.d = mk(rp.ray_d[0], rp.ray_d[1], rp.ray_d[2]);
                 in.ior = rp.ray_ior; in.inside_obj = rp.ray_obj;
             } else {
@@ -1036,6 +1040,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_level(DevScene sc, GEO_PARAMS
                                                       const RayRec* __restrict__ rays_in, RayRec* __restrict__ rays_out,
                                                       NodePool pool, Counters* cnt, TraceOut out) {
     constexpr int RING = T3D_RING;
+    constexpr bool ONE = WAVES != 1;   // the tree of a single ray is traced by one workgroup of several waves; image bands by one-wave workgroups
     __shared__ float4 ring_a_all[WAVES][RING];  // P.xyz, roughness
     __shared__ float4 ring_b_all[WAVES][RING];  // unit normal, int bits: node index within the level
     __shared__ unsigned short pair_ring_all[PAIRS ? WAVES : 1][PAIRS ? T3D_PAIRS : 1];
@@ -1104,13 +1109,13 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_level(DevScene sc, GEO_PARAMS
         } else if (more) {
             // ---------------- trace round: rays chunk*cs + lane and (cs = 128) chunk*cs + 64 + lane ----------------
             RayIn in0, in1;
-            load_ray<LEVEL0>(sc, rp, rays_in, chunk * cs + wc.lane, wc.lane < cs ? n_in : 0, queue_base, in0);
-            load_ray<LEVEL0>(sc, rp, rays_in, chunk * cs + 64 + wc.lane, cs == 128 ? n_in : 0, queue_base, in1);
+            load_ray<LEVEL0, ONE>(sc, rp, rays_in, chunk * cs + wc.lane, wc.lane < cs ? n_in : 0, queue_base, in0);
+            load_ray<LEVEL0, ONE>(sc, rp, rays_in, chunk * cs + 64 + wc.lane, cs == 128 ? n_in : 0, queue_base, in1);
             const bool lights = LEVEL0 ? (rp.lights != 0) : true;
             Hit h0, h1;  // back faces culled iff ray.ior == 1 (T3DR.py:961)
             closest_hit2<LEVEL0>(GEO_ARGS, sc.geo, in0.o, in0.d, in1.o, in1.d, lights, in0.ior == 1.0f, in1.ior == 1.0f, h0, h1);
-            process_ray<LEVEL0, RING, PAIRS>(sc, spheres, rp, wc, in0, h0, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes, &pl);
-            process_ray<LEVEL0, RING, PAIRS>(sc, spheres, rp, wc, in1, h1, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes, &pl);
+            process_ray<LEVEL0, RING, PAIRS, ONE>(sc, spheres, rp, wc, in0, h0, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes, &pl);
+            process_ray<LEVEL0, RING, PAIRS, ONE>(sc, spheres, rp, wc, in1, h1, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes, &pl);
             chunk += chunk_step;
             // the ring is private to this wave; LDS operations of one wave complete in order, the fences
             // only stop the compiler from moving the next round's reads above these writes
