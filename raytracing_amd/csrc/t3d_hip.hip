@@ -124,6 +124,11 @@ struct DevScene {
     const DevLight* lights;    // [L]
     const DevShader* shaders;  // [K]
     const float* obj_ior;      // [O]
+    const float4* prim_info;   // [3 (T + S)]: what the classification of a hit needs about its primitive, gathered in one go
+                               //   row 0: the triangle's un-normalised normal (sphere: its centre), w = ior of the primitive's object
+                               //   row 1: int bits: object, face in its mesh (sphere: -1), shader, kind (bit 0 emitter, bit 1 sphere)
+                               //   row 2: roughness, reflectivity, emission strength (Light: its strength),
+                               //          visibility a shadow ray is left with when this primitive is the first thing it hits
     DevCamera cam;
     float light_color[3];  // sum over lights of colour * 0.6 with saturating adds (T3DR.py:893)
 };
@@ -236,6 +241,16 @@ __device__ __forceinline__ V3 keyed_cube(uint32_t pixel_hash, uint32_t sample_he
 // ------------------------------------------------------------------------------------------------
 // closest hit: Photon.getFirstCollision (T3DR.py:654-730) over every primitive, two rays per lane
 // ------------------------------------------------------------------------------------------------
+#ifdef T3D_COUNT_GROUPS
+// instrumented build only: how many plane groups the closest-hit loops visit, enter and how many triangle steps they run
+struct GroupCount { uint32_t calls, visited, entered, steps; };
+__device__ unsigned long long g_group_count[8];
+#define GC_ADD(gc, field, n) do { if (gc) (gc)->field += (n); } while (0)
+#else
+struct GroupCount;
+#define GC_ADD(gc, field, n) do { } while (0)
+#endif
+
 struct Hit {
     float t;
     int prim;  // < 0 miss; [0, T) triangle (plane-group order); T + s sphere s
@@ -268,7 +283,7 @@ template <int AX, bool NO_CULL>
 __device__ __forceinline__ void plane_groups(const float4* __restrict__ planes, const int* __restrict__ plane_first,
                                              const float4* __restrict__ tri_uv, int g_begin, int g_end, f2 ox, f2 oy, f2 oz,
                                              f2 dx, f2 dy, f2 dz, f2 cull, f2 big, uint32_t& best0, uint32_t& best1, float& A0,
-                                             float& A1, int& bg0, int& bg1) {
+                                             float& A1, int& bg0, int& bg1, GroupCount* gc = nullptr) {
     const f2 os = AX == 0 ? oy : (AX == 1 ? oz : ox), ot = AX == 0 ? oz : (AX == 1 ? ox : oy);
     const f2 ds = AX == 0 ? dy : (AX == 1 ? dz : dx), dt = AX == 0 ? dz : (AX == 1 ? dx : dy);
     for (int g = g_begin; g < g_end; ++g) {
@@ -288,7 +303,10 @@ __device__ __forceinline__ void plane_groups(const float4* __restrict__ planes, 
         const f2 inv = {__builtin_amdgcn_rcpf(dnv.x), __builtin_amdgcn_rcpf(dnv.y)};
         const f2 t = -q * inv;
         const uint32_t tp0 = __float_as_uint(t.x), tp1 = __float_as_uint(t.y);
+        GC_ADD(gc, visited, 1);
         if (!__any((tp0 < best0) | (tp1 < best1))) continue;  // wave-uniform
+        GC_ADD(gc, entered, 1);
+        GC_ADD(gc, steps, (__float_as_int(rk.y) - __float_as_int(rk.x) + 1) / 2);
         const int k0 = __float_as_int(rk.x), k1 = __float_as_int(rk.y);
         const f2 ps = fma2(ds, t, os), pt = fma2(dt, t, ot);
         auto inside = [&](float4 ra, float4 rb) -> f2 {
@@ -353,7 +371,8 @@ __device__ __forceinline__ bool ray_meets_scene_box(const DevGeo& geo, V3 o, V3 
 
 template <bool BOX_FIRST = false, bool NO_CULL = false>
 __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0, V3 d0, V3 o1, V3 d1,
-                                             bool lights, bool back_cull0, bool back_cull1, Hit& out0, Hit& out1) {
+                                             bool lights, bool back_cull0, bool back_cull1, Hit& out0, Hit& out1, GroupCount* gc = nullptr) {
+    GC_ADD(gc, calls, 1);
     const uint32_t INF_BITS = 0x7f800000u;
     const f2 ox = {o0.x, o1.x}, oy = {o0.y, o1.y}, oz = {o0.z, o1.z};
     const f2 dx = {d0.x, d1.x}, dy = {d0.y, d1.y}, dz = {d0.z, d1.z};
@@ -366,9 +385,9 @@ __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0
     int bg0 = 0, bg1 = 0;
     int prim0 = -1, prim1 = -1, back0 = 0, back1 = 0;
     if (any_inside) {
-    plane_groups<0, NO_CULL>(planes, plane_first, tri_uv, 0, geo.axis_end[0], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1);
-    plane_groups<1, NO_CULL>(planes, plane_first, tri_uv, geo.axis_end[0], geo.axis_end[1], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1);
-    plane_groups<2, NO_CULL>(planes, plane_first, tri_uv, geo.axis_end[1], geo.axis_end[2], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1);
+    plane_groups<0, NO_CULL>(planes, plane_first, tri_uv, 0, geo.axis_end[0], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1, gc);
+    plane_groups<1, NO_CULL>(planes, plane_first, tri_uv, geo.axis_end[0], geo.axis_end[1], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1, gc);
+    plane_groups<2, NO_CULL>(planes, plane_first, tri_uv, geo.axis_end[1], geo.axis_end[2], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1, gc);
     if (best0 < INF_BITS) prim0 = first_hit_of_group(plane_first, bg0, A0);
     if (best1 < INF_BITS) prim1 = first_hit_of_group(plane_first, bg1, A1);
     // Spheres and lights.  getSphereCollision (T3DR.py:572-598), Ray.getTSphere (T3DE.py:145-163).
@@ -663,16 +682,8 @@ __device__ __forceinline__ float shadow_facing(const DevScene& sc, const ShadowR
 __device__ __forceinline__ bool shadow_dead(const DevScene& sc, const ShadowRay& s) { return shadow_facing(sc, s) == 0.0f || s.strength == 0.0f; }
 __device__ __forceinline__ float shadow_intensity(const DevScene& sc, const DevSphere* __restrict__ spheres, const ShadowRay& s,
                                                   const Hit& h) {
-    float vis = 1.0f;
-    if (h.prim >= 0) {
-        if (h.prim < sc.n_tris) {
-            DevShader bs = sc.shaders[sc.tri_meta[h.prim].z];
-            if (!(bs.emis > 0.0f)) vis = 1.0f - bs.refl;
-        } else {
-            DevSphere sp = spheres[h.prim - sc.n_tris];
-            if (!sp.is_light) vis = 1.0f - sc.shaders[sp.shader].refl;
-        }
-    }
+    // getVisibility (T3DR.py:762-778): 1 - reflectivity of the first thing hit unless that is a light or an emissive face
+    const float vis = h.prim >= 0 ? sc.prim_info[3 * (size_t)h.prim + 2].w : 1.0f;
     return shadow_facing(sc, s) * s.strength * vis * attenuation(s.dist2);
 }
 
@@ -740,26 +751,25 @@ __device__ __forceinline__ Outcome hit_outcome(const DevScene& sc, const DevSphe
     r.obj = -1; r.face = -1; r.shader = 0; r.dirflag = 0;
     r.emitter = false;
     r.emit = mk(0, 0, 0);
-    float strength = 1.0f;
+    float strength = 1.0f, refl = 1.0f, obj_ior = 1.0f;
+    r.rough = 1.0f;
     if (r.hit) {
-        if (h.prim < sc.n_tris) {
-            int4 meta = sc.tri_meta[h.prim];
-            float4 rn = sc.tri_n[h.prim];
-            r.obj = meta.x; r.face = meta.y; r.shader = meta.z;
-            r.Nraw = mk(rn.x, rn.y, rn.z);
+        const float4* __restrict__ info = sc.prim_info + 3 * (size_t)h.prim;
+        const float4 i0 = info[0], i1 = info[1], i2 = info[2];
+        const int kind = __float_as_int(i1.w);
+        r.obj = __float_as_int(i1.x); r.face = __float_as_int(i1.y); r.shader = __float_as_int(i1.z);
+        if (!(kind & 2)) {
+            r.Nraw = mk(i0.x, i0.y, i0.z);
             r.N = normalize(r.Nraw);
             r.dirflag = (dot(r.Nraw, d) < 0.0f) ? 0 : 1;
-            DevShader sh = sc.shaders[r.shader];
-            r.emitter = sh.emis > 0.0f;
-            strength = sh.emis;
         } else {
-            DevSphere sp = spheres[h.prim - sc.n_tris];
-            r.obj = sp.obj; r.shader = sp.shader; r.dirflag = h.back;
-            r.N = normalize(mk(r.P.x - sp.cx, r.P.y - sp.cy, r.P.z - sp.cz));
+            r.dirflag = h.back;
+            r.N = normalize(mk(r.P.x - i0.x, r.P.y - i0.y, r.P.z - i0.z));
             r.Nraw = r.N;
-            r.emitter = sp.is_light != 0;
-            strength = sp.strength;
         }
+        r.emitter = (kind & 1) != 0;   // an emissive face or a Light
+        strength = i2.z;
+        r.rough = i2.x; refl = i2.y; obj_ior = i0.w;
         if (r.emitter) {
             // computeColor for lights / emissive faces (T3DR.py:1014-1041): distance to the camera
             DevShader sh = sc.shaders[r.shader];
@@ -784,19 +794,16 @@ __device__ __forceinline__ Outcome hit_outcome(const DevScene& sc, const DevSphe
     r.shaded = r.hit && !r.emitter;
     r.want_t = false; r.want_b = false;
     r.tdir = mk(0, 0, 1); r.bdir = mk(0, 0, 1); r.tstart = r.P; r.bstart = r.P;
-    r.t_ior = 1.0f; r.rough = 1.0f;
+    r.t_ior = 1.0f;
     r.t_obj = -1;
     r.child_heap = (in.heap & 0xFFFF0000u) | ((2u * in.heap) & 0xFFFFu);  // bounce child 2n, transmit child 2n + 1
     if (r.shaded) {
-        DevShader sh = sc.shaders[r.shader];
-        const float refl = sh.refl;
-        r.rough = sh.rough;
         const V3 N = r.N, P = r.P;
         if (may_spawn) {
             if (refl != 1.0f) {
                 // transmit (T3DR.py:904-956)
                 V3 Nn = N;
-                float n2 = sc.obj_ior[r.obj];
+                float n2 = obj_ior;
                 int nobj = r.obj;
                 if (r.obj == in.inside_obj) { Nn = N * -1.0f; n2 = 1.0f; nobj = -1; }
                 float cosI = -dot(d, Nn);
@@ -1074,6 +1081,12 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_level(DevScene sc, GEO_PARAMS
     int items_done = 0;  // (node, light) pairs already traced     (wave-uniform)
     const float inv_L = 1.0f / (float)(L > 0 ? L : 1);
     PairList pl{PAIRS ? pair_ring_all[wc.wid] : nullptr, 0, 0u};
+#ifdef T3D_COUNT_GROUPS
+    GroupCount gct{0, 0, 0, 0}, gcs{0, 0, 0, 0};
+    GroupCount *gcp_t = &gct, *gcp_s = &gcs;
+#else
+    GroupCount *gcp_t = nullptr, *gcp_s = nullptr;
+#endif
     for (;;) {
         const int n_items = PAIRS ? pl.tail : ring_nodes * L;
         const int pending = n_items - items_done;
@@ -1101,7 +1114,15 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_level(DevScene sc, GEO_PARAMS
             const ShadowRay s0 = shadow_ray(sc, ring_a[nd0 % RING], rb0, l0);
             const ShadowRay s1 = shadow_ray(sc, ring_a[nd1 % RING], rb1, l1);
             Hit h0, h1;
-            closest_hit2<false, true>(GEO_ARGS, sc.geo, s0.start, s0.Ld, s1.start, s1.Ld, true, false, false, h0, h1);
+            closest_hit2<false, true>(GEO_ARGS, sc.geo, s0.start, s0.Ld, s1.start, s1.Ld, true, false, false, h0, h1, gcp_s);
+#if T3D_EXP == 1
+            {   // experiment: the shadow closest hit a second time
+                Hit g0, g1;
+                closest_hit2<false, true>(GEO_ARGS, sc.geo, madd(s0.start, s0.Ld, 1e-30f * h0.t), s0.Ld, madd(s1.start, s1.Ld, 1e-30f * h1.t), s1.Ld, true, false, false, g0, g1);
+                if (g0.t < 0.0f) h0 = g0;
+                if (g1.t < 0.0f) h1 = g1;
+            }
+#endif
             const float I0 = shadow_intensity(sc, spheres, s0, h0), I1 = shadow_intensity(sc, spheres, s1, h1);
             if (run0) pool.li[(wc.node_base + (size_t)__float_as_int(rb0.w)) * L + l0] = I0;
             if (run1) pool.li[(wc.node_base + (size_t)__float_as_int(rb1.w)) * L + l1] = I1;
@@ -1113,7 +1134,15 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_level(DevScene sc, GEO_PARAMS
             load_ray<LEVEL0, ONE>(sc, rp, rays_in, chunk * cs + 64 + wc.lane, cs == 128 ? n_in : 0, queue_base, in1);
             const bool lights = LEVEL0 ? (rp.lights != 0) : true;
             Hit h0, h1;  // back faces culled iff ray.ior == 1 (T3DR.py:961)
-            closest_hit2<LEVEL0>(GEO_ARGS, sc.geo, in0.o, in0.d, in1.o, in1.d, lights, in0.ior == 1.0f, in1.ior == 1.0f, h0, h1);
+            closest_hit2<LEVEL0>(GEO_ARGS, sc.geo, in0.o, in0.d, in1.o, in1.d, lights, in0.ior == 1.0f, in1.ior == 1.0f, h0, h1, gcp_t);
+#if T3D_EXP == 2
+            {   // experiment: the trace closest hit a second time
+                Hit g0, g1;
+                closest_hit2<LEVEL0>(GEO_ARGS, sc.geo, madd(in0.o, in0.d, 1e-30f * h0.t), in0.d, madd(in1.o, in1.d, 1e-30f * h1.t), in1.d, lights, in0.ior == 1.0f, in1.ior == 1.0f, g0, g1);
+                if (g0.t < 0.0f) h0 = g0;
+                if (g1.t < 0.0f) h1 = g1;
+            }
+#endif
             process_ray<LEVEL0, RING, PAIRS, ONE>(sc, spheres, rp, wc, in0, h0, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes, &pl);
             process_ray<LEVEL0, RING, PAIRS, ONE>(sc, spheres, rp, wc, in1, h1, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes, &pl);
             chunk += chunk_step;
@@ -1126,6 +1155,14 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_level(DevScene sc, GEO_PARAMS
             break;
         }
     }
+#ifdef T3D_COUNT_GROUPS
+    if (wc.lane == 0) {
+        atomicAdd(&g_group_count[0], (unsigned long long)gct.calls); atomicAdd(&g_group_count[1], (unsigned long long)gct.visited);
+        atomicAdd(&g_group_count[2], (unsigned long long)gct.entered); atomicAdd(&g_group_count[3], (unsigned long long)gct.steps);
+        atomicAdd(&g_group_count[4], (unsigned long long)gcs.calls); atomicAdd(&g_group_count[5], (unsigned long long)gcs.visited);
+        atomicAdd(&g_group_count[6], (unsigned long long)gcs.entered); atomicAdd(&g_group_count[7], (unsigned long long)gcs.steps);
+    }
+#endif
     if constexpr (PAIRS) {
         // shadow rays answered without being traced: wave sum, one atomic on the wave's own counter line
         unsigned long long f = pl.culled;
@@ -1481,7 +1518,7 @@ struct t3d_ctx {
     int accel = T3D_ACCEL_AUTO;   // t3d_set_accel
     bool use_bvh = false;         // the uploaded scene is traced through the LBVH
     void* d_tri_meta = nullptr; void* d_spheres = nullptr; void* d_lights = nullptr;
-    void* d_shaders = nullptr; void* d_obj_ior = nullptr;
+    void* d_shaders = nullptr; void* d_obj_ior = nullptr; void* d_prim_info = nullptr;
     int n_objects = 0, n_sphere_objs = 0, n_light_objs = 0;
     // work buffers: one set for image bands, a small one for the tree of a single ray (t3d_trace_pixel / t3d_trace_ray), so
     // that a picked pixel neither frees the band buffers nor invalidates the launch graphs that hold their addresses
@@ -1603,7 +1640,8 @@ static void free_scene(t3d_ctx* c) {
     hipFree(c->d_bvh_nodes); hipFree(c->d_bvh_leaves); hipFree(c->d_bvh_spill);
     c->d_bvh_nodes = c->d_bvh_leaves = c->d_bvh_spill = nullptr; c->use_bvh = false;
     hipFree(c->d_tri_meta); hipFree(c->d_spheres); hipFree(c->d_lights);
-    hipFree(c->d_shaders); hipFree(c->d_obj_ior);
+    hipFree(c->d_shaders); hipFree(c->d_obj_ior); hipFree(c->d_prim_info);
+    c->d_prim_info = nullptr;
     c->d_planes = c->d_plane_first = c->d_tri_uv = c->d_tri_n = nullptr;
     c->d_tri_meta = c->d_spheres = c->d_lights = c->d_shaders = c->d_obj_ior = nullptr;
     c->has_scene = false;
@@ -1855,8 +1893,28 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
         lights[l] = DevLight{(float)s->light_pos[3 * l], (float)s->light_pos[3 * l + 1], (float)s->light_pos[3 * l + 2], (float)s->light_strength[l]};
         for (int ch = 0; ch < 3; ++ch) { lc[ch] += s->light_color[3 * l + ch] * 0.6; if (lc[ch] > 255) lc[ch] = 255; }
     }
+    std::vector<float4> prim_info(3 * ((size_t)s->n_tris + spheres.size()));
+    {
+        auto ib = [](int v) { return __builtin_bit_cast(float, v); };
+        for (int k = 0; k < s->n_tris; ++k) {
+            const int4 m = meta[k];
+            const DevShader& sh = shaders[m.z];
+            const bool emitter = sh.emis > 0.0f;
+            prim_info[3 * (size_t)k + 0] = make_float4(tri_n[k].x, tri_n[k].y, tri_n[k].z, obj_ior[m.x]);
+            prim_info[3 * (size_t)k + 1] = make_float4(ib(m.x), ib(m.y), ib(m.z), ib(emitter ? 1 : 0));
+            prim_info[3 * (size_t)k + 2] = make_float4(sh.rough, sh.refl, sh.emis, emitter ? 1.0f : 1.0f - sh.refl);
+        }
+        for (size_t q = 0; q < spheres.size(); ++q) {
+            const DevSphere& sp = spheres[q];
+            const DevShader& sh = shaders[sp.shader];
+            const size_t k = (size_t)s->n_tris + q;
+            prim_info[3 * k + 0] = make_float4(sp.cx, sp.cy, sp.cz, obj_ior[sp.obj]);
+            prim_info[3 * k + 1] = make_float4(ib(sp.obj), ib(-1), ib(sp.shader), ib(2 | (sp.is_light ? 1 : 0)));
+            prim_info[3 * k + 2] = make_float4(sh.rough, sh.refl, sp.strength, sp.is_light ? 1.0f : 1.0f - sh.refl);
+        }
+    }
     int rc;
-    if ((rc = upload(c, &c->d_planes, planes)) || (rc = upload(c, &c->d_plane_first, plane_first)) || (rc = upload(c, &c->d_tri_uv, tri_uv)) ||
+    if ((rc = upload(c, &c->d_prim_info, prim_info)) || (rc = upload(c, &c->d_planes, planes)) || (rc = upload(c, &c->d_plane_first, plane_first)) || (rc = upload(c, &c->d_tri_uv, tri_uv)) ||
         (rc = upload(c, &c->d_tri_n, tri_n)) || (rc = upload(c, &c->d_tri_meta, meta)) || (rc = upload(c, &c->d_spheres, spheres)) ||
         (rc = upload(c, &c->d_lights, lights)) || (rc = upload(c, &c->d_shaders, shaders)) || (rc = upload(c, &c->d_obj_ior, obj_ior)))
         return rc;
@@ -1914,6 +1972,7 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
     d.n_planes = (int)G; d.n_tris = s->n_tris; d.n_spheres = (int)spheres.size(); d.n_lights = s->n_lights; d.n_shaders = s->n_shaders;
     d.tri_n = (const float4*)c->d_tri_n; d.tri_meta = (const int4*)c->d_tri_meta;
     d.lights = (const DevLight*)c->d_lights; d.shaders = (const DevShader*)c->d_shaders; d.obj_ior = (const float*)c->d_obj_ior;
+    d.prim_info = (const float4*)c->d_prim_info;
     for (int k = 0; k < 3; ++k) { d.cam.pos[k] = (float)s->cam_pos[k]; d.light_color[k] = (float)lc[k]; }
     {   // Euler.toMatrix (T3DE.py:70-94) in float64, rounded once
         double cx = cos(s->cam_euler[0]), sx = sin(s->cam_euler[0]), cy = cos(s->cam_euler[1]), sy = sin(s->cam_euler[1]);
@@ -2028,6 +2087,15 @@ static void fill_stats(t3d_ctx* c, t3d_stats* stats) {
         stats->sphere_tests += (q - culled) * (uint64_t)c->sc.n_spheres - (c->last_lights ? 0 : c->last_n0 * (uint64_t)c->n_light_objs);
     }
     stats->nodes += nodes;  // shaded nodes only; emitter leaves are folded into their parents
+#ifdef T3D_COUNT_GROUPS
+    {
+        unsigned long long g[8] = {0}, z[8] = {0};
+        hipMemcpyFromSymbol(g, HIP_SYMBOL(g_group_count), sizeof(g));
+        hipMemcpyToSymbol(HIP_SYMBOL(g_group_count), z, sizeof(z));
+        fprintf(stderr, "group counts  trace: rounds %llu groups visited %llu entered %llu triangle steps %llu   shadow: rounds %llu visited %llu entered %llu steps %llu\n",
+                g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
+    }
+#endif
     stats->launches += c->last_launches;
     stats->n_k_level += (uint64_t)levels;
 }
