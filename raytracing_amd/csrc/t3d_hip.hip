@@ -722,23 +722,36 @@ struct RayIn {
 };
 
 // What the closest hit of a ray leads to (per lane, no communication): classification (miss / emitter leaf / shaded
-// node), the colour of an emitter leaf, and the bounce and transmit rays of a shaded node.
+// node), the colour of an emitter leaf, and whether a shaded node gets a reflected and a transmitted child.  The child rays
+// themselves are worked out later (child_rays), once the wave has reserved their slots, so that the classification of
+// several rays of a lane can be kept in registers side by side.
 struct Outcome {
     bool hit, emitter, shaded, want_t, want_b;
-    V3 P, N, Nraw, emit;          // hit point; unit normal as bounce / transmit / direct light use it; normal as the reference stores it
+    V3 P, N;                      // hit point; unit normal as bounce / transmit / direct light use it
+    V3 Nraw, emit;                // normal as the reference stores it (debug records); colour of an emitter leaf
     int obj, face, shader, dirflag;
-    float att_parent, rough, t_ior;
-    int t_obj;
+    float att_parent, rough, obj_ior;
+};
+struct ChildRays {
     V3 tdir, bdir, tstart, bstart;
+    float t_ior;
+    int t_obj;
     uint32_t child_heap;          // heap key of the bounce child (2n); the transmit child is 2n + 1
 };
+
+// The medium on the far side of the surface a ray meets (T3DR.py:915-927): leaving the object the ray travels in, the
+// normal is flipped and the ray enters air
+__device__ __forceinline__ void transmit_side(const Outcome& r, const RayIn& in, V3& Nn, float& n2, int& nobj) {
+    Nn = r.N; n2 = r.obj_ior; nobj = r.obj;
+    if (r.obj == in.inside_obj) { Nn = r.N * -1.0f; n2 = 1.0f; nobj = -1; }
+}
 
 // level0: the ray is a primary ray (its leaf colours go to the pixel, its hit to the primary-id outputs);
 // may_spawn: the ray's level is below options['bounces'] (T3DR.py:976-977)
 // ONE: the launch may be the tree of a single ray (t3d_trace_pixel / t3d_trace_ray); kernels that only ever trace image
 // bands say so, and the parameters of that mode are not kept in registers
 template <bool ONE = true>
-__device__ __forceinline__ Outcome hit_outcome(const DevScene& sc, const DevSphere* __restrict__ spheres, const RenderParams& rp,
+__device__ __forceinline__ Outcome hit_outcome(const DevScene& sc, const RenderParams& rp,
                                                const RayIn& in, const Hit& h, bool level0, bool may_spawn, const TraceOut& out) {
     const int single = ONE ? rp.single : 0;
     Outcome r;
@@ -751,8 +764,8 @@ __device__ __forceinline__ Outcome hit_outcome(const DevScene& sc, const DevSphe
     r.obj = -1; r.face = -1; r.shader = 0; r.dirflag = 0;
     r.emitter = false;
     r.emit = mk(0, 0, 0);
-    float strength = 1.0f, refl = 1.0f, obj_ior = 1.0f;
-    r.rough = 1.0f;
+    float strength = 1.0f, refl = 1.0f;
+    r.rough = 1.0f; r.obj_ior = 1.0f;
     if (r.hit) {
         const float4* __restrict__ info = sc.prim_info + 3 * (size_t)h.prim;
         const float4 i0 = info[0], i1 = info[1], i2 = info[2];
@@ -769,7 +782,7 @@ __device__ __forceinline__ Outcome hit_outcome(const DevScene& sc, const DevSphe
         }
         r.emitter = (kind & 1) != 0;   // an emissive face or a Light
         strength = i2.z;
-        r.rough = i2.x; refl = i2.y; obj_ior = i0.w;
+        r.rough = i2.x; refl = i2.y; r.obj_ior = i0.w;
         if (r.emitter) {
             // computeColor for lights / emissive faces (T3DR.py:1014-1041): distance to the camera
             DevShader sh = sc.shaders[r.shader];
@@ -790,50 +803,57 @@ __device__ __forceinline__ Outcome hit_outcome(const DevScene& sc, const DevSphe
     V3 pp = r.P - in.pstart;
     r.att_parent = level0 ? 1.0f : attenuation(dot(pp, pp));
 
-    // ---- shaded node and its children (T3DR.py:979-995) --------------------------------------
+    // ---- shaded node: which children it gets (T3DR.py:979-995) --------------------------------------
     r.shaded = r.hit && !r.emitter;
     r.want_t = false; r.want_b = false;
-    r.tdir = mk(0, 0, 1); r.bdir = mk(0, 0, 1); r.tstart = r.P; r.bstart = r.P;
-    r.t_ior = 1.0f;
-    r.t_obj = -1;
-    r.child_heap = (in.heap & 0xFFFF0000u) | ((2u * in.heap) & 0xFFFFu);  // bounce child 2n, transmit child 2n + 1
-    if (r.shaded) {
-        const V3 N = r.N, P = r.P;
-        if (may_spawn) {
-            if (refl != 1.0f) {
-                // transmit (T3DR.py:904-956)
-                V3 Nn = N;
-                float n2 = obj_ior;
-                int nobj = r.obj;
-                if (r.obj == in.inside_obj) { Nn = N * -1.0f; n2 = 1.0f; nobj = -1; }
-                float cosI = -dot(d, Nn);
-                float ratio = in.ior * __builtin_amdgcn_rcpf(n2);
-                float sin2T = ratio * ratio * (1.0f - cosI * cosI);
-                if (!(sin2T > 1.0f)) {
-                    float cosT = __builtin_amdgcn_sqrtf(1.0f - sin2T);
-                    V3 spec = madd(d * ratio, Nn, ratio * cosI - cosT);
-                    V3 diff = normalize(keyed_cube(in.pixel_hash, r.child_heap + 1u));
-                    if (dot(diff, Nn) > 0.0f) diff = diff * -1.0f;
-                    V3 dir = madd(spec * (1.0f - r.rough), diff, r.rough);
-                    r.tstart = madd(P, dir, 0.1f);
-                    r.tdir = normalize(dir);
-                    r.t_ior = n2; r.t_obj = nobj;
-                    r.want_t = true;
-                }
-            }
-            if (refl != 0.0f) {
-                // bounce (T3DR.py:733-759)
-                V3 diff = normalize(keyed_cube(in.pixel_hash, r.child_heap));
-                if (dot(diff, N) < 0.0f) diff = diff * -1.0f;
-                V3 spec = madd(d, N, -2.0f * dot(d, N));
-                V3 dir = madd(spec * (1.0f - r.rough), diff, r.rough);
-                r.bstart = madd(P, dir, 0.1f);
-                r.bdir = normalize(dir);
-                r.want_b = true;
-            }
+    if (r.shaded && may_spawn) {
+        if (refl != 1.0f) {
+            // transmit (T3DR.py:904-956): no child on total internal reflection
+            V3 Nn; float n2; int nobj;
+            transmit_side(r, in, Nn, n2, nobj);
+            const float cosI = -dot(d, Nn);
+            const float ratio = in.ior * __builtin_amdgcn_rcpf(n2);
+            const float sin2T = ratio * ratio * (1.0f - cosI * cosI);
+            r.want_t = !(sin2T > 1.0f);
         }
+        r.want_b = refl != 0.0f;
     }
     return r;
+}
+
+// The bounce and transmit rays of a shaded node (those its classification asked for).
+__device__ __forceinline__ ChildRays child_rays(const Outcome& r, const RayIn& in) {
+    ChildRays c;
+    const V3 d = in.d, N = r.N, P = r.P;
+    c.tdir = mk(0, 0, 1); c.bdir = mk(0, 0, 1); c.tstart = P; c.bstart = P;
+    c.t_ior = 1.0f; c.t_obj = -1;
+    c.child_heap = (in.heap & 0xFFFF0000u) | ((2u * in.heap) & 0xFFFFu);  // bounce child 2n, transmit child 2n + 1
+    if (r.want_t) {
+        // transmit (T3DR.py:904-956)
+        V3 Nn; float n2; int nobj;
+        transmit_side(r, in, Nn, n2, nobj);
+        const float cosI = -dot(d, Nn);
+        const float ratio = in.ior * __builtin_amdgcn_rcpf(n2);
+        const float sin2T = ratio * ratio * (1.0f - cosI * cosI);
+        const float cosT = __builtin_amdgcn_sqrtf(1.0f - sin2T);
+        V3 spec = madd(d * ratio, Nn, ratio * cosI - cosT);
+        V3 diff = normalize(keyed_cube(in.pixel_hash, c.child_heap + 1u));
+        if (dot(diff, Nn) > 0.0f) diff = diff * -1.0f;
+        V3 dir = madd(spec * (1.0f - r.rough), diff, r.rough);
+        c.tstart = madd(P, dir, 0.1f);
+        c.tdir = normalize(dir);
+        c.t_ior = n2; c.t_obj = nobj;
+    }
+    if (r.want_b) {
+        // bounce (T3DR.py:733-759)
+        V3 diff = normalize(keyed_cube(in.pixel_hash, c.child_heap));
+        if (dot(diff, N) < 0.0f) diff = diff * -1.0f;
+        V3 spec = madd(d, N, -2.0f * dot(d, N));
+        V3 dir = madd(spec * (1.0f - r.rough), diff, r.rough);
+        c.bstart = madd(P, dir, 0.1f);
+        c.bdir = normalize(dir);
+    }
+    return c;
 }
 
 // The wave's list of shadow rays still to trace, when the scene has few lights (PAIRS): (ring slot of the node, light),
@@ -844,140 +864,173 @@ struct PairList {
     uint32_t culled;        // pairs answered without a ray, this lane
 };
 
-// Everything that follows the closest hit of ONE ray per lane (wave-collective: ballots and atomics):
-// classification, emitter / miss leaves, bounce and transmit rays, node record, queue appends, ring entry.
-template <bool LEVEL0, int RING, bool PAIRS = false, bool ONE = true>
-__device__ __forceinline__ void process_ray(const DevScene& sc, const DevSphere* __restrict__ spheres, const RenderParams& rp,
-                                            const WaveCtx& wc, const RayIn& in, const Hit& h, RayRec* __restrict__ rays_out,
-                                            const NodePool& pool, Counters* cnt, const TraceOut& out, float4* ring_a,
-                                            float4* ring_b, int& ring_nodes, PairList* pl = nullptr) {
-    const Outcome oc = hit_outcome<ONE>(sc, spheres, rp, in, h, LEVEL0, wc.level < rp.bounces, out);
+// Everything that follows the closest hits of the NR rays of a lane (wave-collective: ballots and atomics):
+// classification, emitter / miss leaves, bounce and transmit rays, node records, queue appends, ring entries.
+// The rays of a lane are classified first -- the gathers of all of them are in flight together -- and the wave then
+// reserves its node and ray slots with ONE atomic per counter: nodes of ray 0 of every lane in lane order, then those of
+// ray 1; child rays as (transmitted, reflected) of ray 0, then of ray 1.
+template <bool LEVEL0, int RING, bool PAIRS = false, bool ONE = true, int NR = 1>
+__device__ __forceinline__ void process_rays(const DevScene& sc, const DevSphere* __restrict__ spheres, const RenderParams& rp,
+                                             const WaveCtx& wc, const RayIn (&in)[NR], const Hit (&h)[NR], RayRec* __restrict__ rays_out,
+                                             const NodePool& pool, Counters* cnt, const TraceOut& out, float4* ring_a,
+                                             float4* ring_b, int& ring_nodes, PairList* pl = nullptr) {
     const bool want_debug = ONE && rp.want_debug;
-    const V3 o = in.o, d = in.d, P = oc.P, N = oc.N, emit = oc.emit;
-    const bool hit = oc.hit, emitter = oc.emitter, shaded = oc.shaded, want_t = oc.want_t, want_b = oc.want_b;
-    const int shader = oc.shader;
-    const float att_parent = oc.att_parent, rough = oc.rough, t_ior = oc.t_ior;
-    const int t_obj = oc.t_obj;
-    const V3 tdir = oc.tdir, bdir = oc.bdir, tstart = oc.tstart, bstart = oc.bstart;
-    const uint32_t child_heap = oc.child_heap;
+    Outcome oc[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) oc[r] = hit_outcome<ONE>(sc, rp, in[r], h[r], LEVEL0, wc.level < rp.bounces, out);
 
-    // ---- debug record (single-pixel mode) ----------------------------------------------
-    int dbg_idx = -1;
-    if (want_debug && hit) {
-        dbg_idx = atomicAdd(&cnt->n_dbg, 1);
-        if (dbg_idx < out.dbg_cap) {
-            t3d_node& nd = out.dbg[dbg_idx];
-            nd.heap = (int)(in.heap & 0xFFFFu); nd.obj = oc.obj; nd.face = oc.face; nd.direction = oc.dirflag; nd.t = h.t;
-            nd.point[0] = P.x; nd.point[1] = P.y; nd.point[2] = P.z;
-            nd.normal[0] = oc.Nraw.x; nd.normal[1] = oc.Nraw.y; nd.normal[2] = oc.Nraw.z;
-            nd.ray_start[0] = o.x; nd.ray_start[1] = o.y; nd.ray_start[2] = o.z;
-            nd.ray_dir[0] = d.x; nd.ray_dir[1] = d.y; nd.ray_dir[2] = d.z;
-            nd.ray_ior = in.ior; nd.ray_obj = in.inside_obj;
-            nd.color[0] = emit.x; nd.color[1] = emit.y; nd.color[2] = emit.z;
+    // ---- debug records (single-pixel mode) ----------------------------------------------
+    int dbg_idx[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        dbg_idx[r] = -1;
+        if (want_debug && oc[r].hit) {
+            dbg_idx[r] = atomicAdd(&cnt->n_dbg, 1);
+            if (dbg_idx[r] < out.dbg_cap) {
+                t3d_node& nd = out.dbg[dbg_idx[r]];
+                const V3 P = oc[r].P, o = in[r].o, d = in[r].d, emit = oc[r].emit;
+                nd.heap = (int)(in[r].heap & 0xFFFFu); nd.obj = oc[r].obj; nd.face = oc[r].face; nd.direction = oc[r].dirflag; nd.t = h[r].t;
+                nd.point[0] = P.x; nd.point[1] = P.y; nd.point[2] = P.z;
+                nd.normal[0] = oc[r].Nraw.x; nd.normal[1] = oc[r].Nraw.y; nd.normal[2] = oc[r].Nraw.z;
+                nd.ray_start[0] = o.x; nd.ray_start[1] = o.y; nd.ray_start[2] = o.z;
+                nd.ray_dir[0] = d.x; nd.ray_dir[1] = d.y; nd.ray_dir[2] = d.z;
+                nd.ray_ior = in[r].ior; nd.ray_obj = in[r].inside_obj;
+                nd.color[0] = emit.x; nd.color[1] = emit.y; nd.color[2] = emit.z;
+            }
         }
     }
 
     // ---- leaves -------------------------------------------------------------------------
-    if (in.active && (!hit || emitter)) {
-        if (LEVEL0) {
-            V3 c = hit ? emit : mk(rp.ambient[0], rp.ambient[1], rp.ambient[2]);  // T3DR.py:1006-1007
-            if (out.bgr) store_pixel(out.bgr, out.radiance, in.i, c.x, c.y, c.z, 1.0f);
-            else out.sample_color[in.i] = make_float4(c.x, c.y, c.z, 0.0f);
-        } else if (hit) {
-            float4* slot = in.side ? pool.d : pool.c;
-            *(float3*)&slot[in.parent] = make_float3(emit.x * att_parent, emit.y * att_parent, emit.z * att_parent);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        if (in[r].active && (!oc[r].hit || oc[r].emitter)) {
+            const V3 emit = oc[r].emit;
+            if (LEVEL0) {
+                V3 c = oc[r].hit ? emit : mk(rp.ambient[0], rp.ambient[1], rp.ambient[2]);  // T3DR.py:1006-1007
+                if (out.bgr) store_pixel(out.bgr, out.radiance, in[r].i, c.x, c.y, c.z, 1.0f);
+                else out.sample_color[in[r].i] = make_float4(c.x, c.y, c.z, 0.0f);
+            } else if (oc[r].hit) {
+                const float att_parent = oc[r].att_parent;
+                float4* slot = in[r].side ? pool.d : pool.c;
+                *(float3*)&slot[in[r].parent] = make_float3(emit.x * att_parent, emit.y * att_parent, emit.z * att_parent);
+            }
         }
     }
 
-    // ---- append: node slot and child-ray slots (wave64 ballot + prefix popcount) --------------------
-    const unsigned long long m_n = __ballot(shaded), m_t = __ballot(want_t), m_b = __ballot(want_b);
-    const int c_n = __popcll(m_n), c_t = __popcll(m_t), c_b = __popcll(m_b);
+    // ---- append: node slots and child-ray slots (wave64 ballot + prefix popcount) --------------------
+    unsigned long long m_n[NR], m_t[NR], m_b[NR];
+    int c_n = 0, c_r = 0;
+    int off_n[NR], off_t[NR], off_b[NR];   // where this lane's entries go, relative to the wave's reservation
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        m_n[r] = __ballot(oc[r].shaded); m_t[r] = __ballot(oc[r].want_t); m_b[r] = __ballot(oc[r].want_b);
+        off_n[r] = c_n + __popcll(m_n[r] & wc.lt_mask); c_n += __popcll(m_n[r]);
+        off_t[r] = c_r + __popcll(m_t[r] & wc.lt_mask); c_r += __popcll(m_t[r]);
+        off_b[r] = c_r + __popcll(m_b[r] & wc.lt_mask); c_r += __popcll(m_b[r]);
+    }
     int base_n = 0, base_r = 0;
     if (wc.lane == 0) {   // both atomics are issued before either result is needed
         if (c_n) base_n = atomicAdd(&cnt->n_nodes[wc.level][wc.shard].v, c_n);
-        if (c_t + c_b) base_r = atomicAdd(&cnt->n_rays[wc.level + 1][wc.shard].v, c_t + c_b);
+        if (c_r) base_r = atomicAdd(&cnt->n_rays[wc.level + 1][wc.shard].v, c_r);
+    }
+    // Few lights (PAIRS): which of them can add anything at a node?  Only those (node, light) pairs are listed for the
+    // shadow rounds, node after node; the node record says which, so the others' intensities are never read.
+    // (worked out while the atomics are on their way)
+    uint32_t live[NR];
+    int pair_pos[NR], pairs_total = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        live[r] = 0; pair_pos[r] = 0;
+        if constexpr (RING > 0 && PAIRS) {
+            const float4 ra = make_float4(oc[r].P.x, oc[r].P.y, oc[r].P.z, oc[r].rough), rb = make_float4(oc[r].N.x, oc[r].N.y, oc[r].N.z, 0.0f);
+            pair_pos[r] = pairs_total;
+            for (int l = 0; l < wc.L; ++l) {
+                const bool lv = oc[r].shaded && !shadow_dead(sc, shadow_ray(sc, ra, rb, l));
+                const unsigned long long m = __ballot(lv);
+                pair_pos[r] += __popcll(m & wc.lt_mask);
+                pairs_total += __popcll(m);
+                live[r] |= (uint32_t)lv << l;
+            }
+        }
     }
     base_n = __shfl(base_n, 0);
     base_r = __shfl(base_r, 0);
-    const int nrank = __popcll(m_n & wc.lt_mask);
-    const int nloc = base_n + nrank;                                  // index within the shard
-    const int tloc = base_r + __popcll(m_t & wc.lt_mask);
-    const int bloc = base_r + c_t + __popcll(m_b & wc.lt_mask);
-    const int node = wc.shard * wc.shard_cap + nloc;                  // index within the level
-    const bool stored = shaded && nloc < wc.shard_cap;
-    if (shaded && !stored) { cnt->overflow = 1; rp.sticky[0] = 1; }
-    // Few lights (PAIRS): which of them can add anything at this node?  Only those (node, light) pairs are listed for the
-    // shadow rounds, node after node in lane order; the node record says which, so the others' intensities are never read.
-    uint32_t live = 0;
-    int pairs_before = 0, pairs_total = 0;
-    if constexpr (RING > 0 && PAIRS) {
-        const float4 ra = make_float4(P.x, P.y, P.z, rough), rb = make_float4(N.x, N.y, N.z, 0.0f);
-        for (int l = 0; l < wc.L; ++l) {
-            const bool lv = shaded && !shadow_dead(sc, shadow_ray(sc, ra, rb, l));
-            const unsigned long long m = __ballot(lv);
-            pairs_before += __popcll(m & wc.lt_mask);
-            pairs_total += __popcll(m);
-            live |= (uint32_t)lv << l;
+    int node[NR];
+    bool stored[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int nloc = base_n + off_n[r];                            // index within the shard
+        node[r] = wc.shard * wc.shard_cap + nloc;                      // index within the level
+        stored[r] = oc[r].shaded && nloc < wc.shard_cap;
+        if (oc[r].shaded && !stored[r]) { cnt->overflow = 1; rp.sticky[0] = 1; }
+        if (stored[r]) {
+            const float k = 2.0f / 255.0f;  // absent children count as ambient * 2/255 (T3DR.py:1054-1055)
+            const size_t g = wc.node_base + (size_t)node[r];
+            pool.c[g] = make_float4(rp.ambient[0] * k, rp.ambient[1] * k, rp.ambient[2] * k, oc[r].att_parent);
+            pool.d[g] = make_float4(rp.ambient[0] * k, rp.ambient[1] * k, rp.ambient[2] * k,
+                                    __int_as_float(oc[r].shader | (int)(live[r] << T3D_LIVE_SHIFT) | (in[r].side << 30)));
+            pool.parent[g] = in[r].parent;
+            if (want_debug) pool.dbg[g] = dbg_idx[r];
+        }
+        const V3 o = in[r].o;
+        const ChildRays ch = child_rays(oc[r], in[r]);
+        if (oc[r].want_t && stored[r]) {
+            const int tloc = base_r + off_t[r];
+            if (tloc < wc.shard_cap) {
+                RayRec q;
+                q.o = make_float4(ch.tstart.x, ch.tstart.y, ch.tstart.z, ch.t_ior);
+                q.d = make_float4(ch.tdir.x, ch.tdir.y, ch.tdir.z, __int_as_float(ch.t_obj));
+                q.p = make_float4(o.x, o.y, o.z, __int_as_float((int)(wc.node_base + node[r])));
+                q.k = make_uint4(in[r].ps, ch.child_heap + 1u, 1u, in[r].pixel_hash);
+                rays_out[wc.shard * wc.shard_cap + tloc] = q;
+            } else { cnt->overflow = 1; rp.sticky[0] = 1; }
+        }
+        if (oc[r].want_b && stored[r]) {
+            const int bloc = base_r + off_b[r];
+            if (bloc < wc.shard_cap) {
+                RayRec q;
+                q.o = make_float4(ch.bstart.x, ch.bstart.y, ch.bstart.z, in[r].ior);
+                q.d = make_float4(ch.bdir.x, ch.bdir.y, ch.bdir.z, __int_as_float(in[r].inside_obj));
+                q.p = make_float4(o.x, o.y, o.z, __int_as_float((int)(wc.node_base + node[r])));
+                q.k = make_uint4(in[r].ps, ch.child_heap, 0u, in[r].pixel_hash);
+                rays_out[wc.shard * wc.shard_cap + bloc] = q;
+            } else { cnt->overflow = 1; rp.sticky[0] = 1; }
         }
     }
-    if (stored) {
-        const float k = 2.0f / 255.0f;  // absent children count as ambient * 2/255 (T3DR.py:1054-1055)
-        const size_t g = wc.node_base + (size_t)node;
-        pool.c[g] = make_float4(rp.ambient[0] * k, rp.ambient[1] * k, rp.ambient[2] * k, att_parent);
-        pool.d[g] = make_float4(rp.ambient[0] * k, rp.ambient[1] * k, rp.ambient[2] * k,
-                                __int_as_float(shader | (int)(live << T3D_LIVE_SHIFT) | (in.side << 30)));
-        pool.parent[g] = in.parent;
-        if (want_debug) pool.dbg[g] = dbg_idx;
-    }
-    if (want_t && stored) {
-        if (tloc < wc.shard_cap) {
-            RayRec r;
-            r.o = make_float4(tstart.x, tstart.y, tstart.z, t_ior);
-            r.d = make_float4(tdir.x, tdir.y, tdir.z, __int_as_float(t_obj));
-            r.p = make_float4(o.x, o.y, o.z, __int_as_float((int)(wc.node_base + node)));
-            r.k = make_uint4(in.ps, child_heap + 1u, 1u, in.pixel_hash);
-            rays_out[wc.shard * wc.shard_cap + tloc] = r;
-        } else { cnt->overflow = 1; rp.sticky[0] = 1; }
-    }
-    if (want_b && stored) {
-        if (bloc < wc.shard_cap) {
-            RayRec r;
-            r.o = make_float4(bstart.x, bstart.y, bstart.z, in.ior);
-            r.d = make_float4(bdir.x, bdir.y, bdir.z, __int_as_float(in.inside_obj));
-            r.p = make_float4(o.x, o.y, o.z, __int_as_float((int)(wc.node_base + node)));
-            r.k = make_uint4(in.ps, child_heap, 0u, in.pixel_hash);
-            rays_out[wc.shard * wc.shard_cap + bloc] = r;
-        } else { cnt->overflow = 1; rp.sticky[0] = 1; }
-    }
-    if constexpr (RING > 0 && PAIRS) {
-        // only nodes with a listed pair enter the ring
-        const unsigned long long m_r = __ballot(live != 0);
-        if (live) {
-            const int slot = (ring_nodes + __popcll(m_r & wc.lt_mask)) % RING;
-            ring_a[slot] = make_float4(P.x, P.y, P.z, rough);
-            ring_b[slot] = make_float4(N.x, N.y, N.z, __int_as_float(stored ? node : 0));
-            const int pos = pl->tail + pairs_before;
-            for (int l = 0; l < wc.L; ++l)
-                if ((live >> l) & 1u) pl->ring[(pos + __popc(live & ((1u << l) - 1u))) % T3D_PAIRS] = (unsigned short)(slot | (l << 8));
-        }
-        if (shaded) pl->culled += (uint32_t)(wc.L - __popc(live));
-        ring_nodes += __popcll(m_r);
-        pl->tail += pairs_total;
-    } else if constexpr (RING > 0) {
-        // shaded nodes enter the wave's ring in lane order
-        if (shaded && wc.L > 0) {
-            const int slot = (ring_nodes + nrank) % RING;
-            ring_a[slot] = make_float4(P.x, P.y, P.z, rough);
-            ring_b[slot] = make_float4(N.x, N.y, N.z, __int_as_float(stored ? node : 0));
-        }
-        ring_nodes += c_n;
-    } else {
-        // no ring: ring_a / ring_b are arrays in global memory indexed by the node's position in its level
-        if (stored && wc.L > 0) {
-            ring_a[node] = make_float4(P.x, P.y, P.z, rough);
-            ring_b[node] = make_float4(N.x, N.y, N.z, 0.0f);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const V3 P = oc[r].P, N = oc[r].N;
+        const float rough = oc[r].rough;
+        if constexpr (RING > 0 && PAIRS) {
+            // only nodes with a listed pair enter the ring
+            const unsigned long long m_r = __ballot(live[r] != 0);
+            if (live[r]) {
+                const int slot = (ring_nodes + __popcll(m_r & wc.lt_mask)) % RING;
+                ring_a[slot] = make_float4(P.x, P.y, P.z, rough);
+                ring_b[slot] = make_float4(N.x, N.y, N.z, __int_as_float(stored[r] ? node[r] : 0));
+                const int pos = pl->tail + pair_pos[r];
+                for (int l = 0; l < wc.L; ++l)
+                    if ((live[r] >> l) & 1u) pl->ring[(pos + __popc(live[r] & ((1u << l) - 1u))) % T3D_PAIRS] = (unsigned short)(slot | (l << 8));
+            }
+            if (oc[r].shaded) pl->culled += (uint32_t)(wc.L - __popc(live[r]));
+            ring_nodes += __popcll(m_r);
+        } else if constexpr (RING > 0) {
+            // shaded nodes enter the wave's ring in lane order
+            if (oc[r].shaded && wc.L > 0) {
+                const int slot = (ring_nodes + __popcll(m_n[r] & wc.lt_mask)) % RING;
+                ring_a[slot] = make_float4(P.x, P.y, P.z, rough);
+                ring_b[slot] = make_float4(N.x, N.y, N.z, __int_as_float(stored[r] ? node[r] : 0));
+            }
+            ring_nodes += __popcll(m_n[r]);
+        } else {
+            // no ring: ring_a / ring_b are arrays in global memory indexed by the node's position in its level
+            if (stored[r] && wc.L > 0) {
+                ring_a[node[r]] = make_float4(P.x, P.y, P.z, rough);
+                ring_b[node[r]] = make_float4(N.x, N.y, N.z, 0.0f);
+            }
         }
     }
+    if constexpr (RING > 0 && PAIRS) pl->tail += pairs_total;
 }
 
 template <bool LEVEL0, bool ONE = true>
@@ -1129,22 +1182,21 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_level(DevScene sc, GEO_PARAMS
             items_done += pending < 128 ? pending : 128;
         } else if (more) {
             // ---------------- trace round: rays chunk*cs + lane and (cs = 128) chunk*cs + 64 + lane ----------------
-            RayIn in0, in1;
-            load_ray<LEVEL0, ONE>(sc, rp, rays_in, chunk * cs + wc.lane, wc.lane < cs ? n_in : 0, queue_base, in0);
-            load_ray<LEVEL0, ONE>(sc, rp, rays_in, chunk * cs + 64 + wc.lane, cs == 128 ? n_in : 0, queue_base, in1);
+            RayIn in[2];
+            load_ray<LEVEL0, ONE>(sc, rp, rays_in, chunk * cs + wc.lane, wc.lane < cs ? n_in : 0, queue_base, in[0]);
+            load_ray<LEVEL0, ONE>(sc, rp, rays_in, chunk * cs + 64 + wc.lane, cs == 128 ? n_in : 0, queue_base, in[1]);
             const bool lights = LEVEL0 ? (rp.lights != 0) : true;
-            Hit h0, h1;  // back faces culled iff ray.ior == 1 (T3DR.py:961)
-            closest_hit2<LEVEL0>(GEO_ARGS, sc.geo, in0.o, in0.d, in1.o, in1.d, lights, in0.ior == 1.0f, in1.ior == 1.0f, h0, h1, gcp_t);
+            Hit h[2];  // back faces culled iff ray.ior == 1 (T3DR.py:961)
+            closest_hit2<LEVEL0>(GEO_ARGS, sc.geo, in[0].o, in[0].d, in[1].o, in[1].d, lights, in[0].ior == 1.0f, in[1].ior == 1.0f, h[0], h[1], gcp_t);
 #if T3D_EXP == 2
             {   // experiment: the trace closest hit a second time
                 Hit g0, g1;
-                closest_hit2<LEVEL0>(GEO_ARGS, sc.geo, madd(in0.o, in0.d, 1e-30f * h0.t), in0.d, madd(in1.o, in1.d, 1e-30f * h1.t), in1.d, lights, in0.ior == 1.0f, in1.ior == 1.0f, g0, g1);
-                if (g0.t < 0.0f) h0 = g0;
-                if (g1.t < 0.0f) h1 = g1;
+                closest_hit2<LEVEL0>(GEO_ARGS, sc.geo, madd(in[0].o, in[0].d, 1e-30f * h[0].t), in[0].d, madd(in[1].o, in[1].d, 1e-30f * h[1].t), in[1].d, lights, in[0].ior == 1.0f, in[1].ior == 1.0f, g0, g1);
+                if (g0.t < 0.0f) h[0] = g0;
+                if (g1.t < 0.0f) h[1] = g1;
             }
 #endif
-            process_ray<LEVEL0, RING, PAIRS, ONE>(sc, spheres, rp, wc, in0, h0, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes, &pl);
-            process_ray<LEVEL0, RING, PAIRS, ONE>(sc, spheres, rp, wc, in1, h1, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes, &pl);
+            process_rays<LEVEL0, RING, PAIRS, ONE, 2>(sc, spheres, rp, wc, in, h, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes, &pl);
             chunk += chunk_step;
             // the ring is private to this wave; LDS operations of one wave complete in order, the fences
             // only stop the compiler from moving the next round's reads above these writes
@@ -1287,15 +1339,15 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_bvh_process(DevScene sc, const De
     const int chunk_step = LEVEL0 ? nw : nw >> rp.shard_bits;
     int unused = 0;
     for (int chunk = LEVEL0 ? gw : gw >> rp.shard_bits; (long long)chunk * 64 < n_in; chunk += chunk_step) {
-        RayIn in;
-        load_ray<LEVEL0>(sc, rp, rays_in, chunk * 64 + wc.lane, n_in, queue_base, in);
-        Hit h;
-        h.t = __builtin_inff(); h.prim = -1; h.back = 0;
-        if (in.active) {
-            const uint2 r = hits[in.i];
-            h.t = __uint_as_float(r.x & 0x7fffffffu); h.back = (int)(r.x >> 31); h.prim = (int)r.y;
+        RayIn in[1];
+        load_ray<LEVEL0>(sc, rp, rays_in, chunk * 64 + wc.lane, n_in, queue_base, in[0]);
+        Hit h[1];
+        h[0].t = __builtin_inff(); h[0].prim = -1; h[0].back = 0;
+        if (in[0].active) {
+            const uint2 r = hits[in[0].i];
+            h[0].t = __uint_as_float(r.x & 0x7fffffffu); h[0].back = (int)(r.x >> 31); h[0].prim = (int)r.y;
         }
-        process_ray<LEVEL0, 0>(sc, spheres, rp, wc, in, h, rays_out, pool, cnt, out, src_a, src_b, unused);
+        process_rays<LEVEL0, 0>(sc, spheres, rp, wc, in, h, rays_out, pool, cnt, out, src_a, src_b, unused);
     }
 }
 
