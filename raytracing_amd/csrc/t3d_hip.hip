@@ -303,6 +303,9 @@ __device__ __forceinline__ void plane_groups(const float4* __restrict__ planes, 
         const f2 inv = {__builtin_amdgcn_rcpf(dnv.x), __builtin_amdgcn_rcpf(dnv.y)};
         const f2 t = -q * inv;
         const uint32_t tp0 = __float_as_uint(t.x), tp1 = __float_as_uint(t.y);
+        // four of five groups are entered: their range and first rows are asked for together with the plane row (this empty
+        // statement needs them, so the requests stay in front of the branch)
+        asm volatile("" :: "s"(rk.w), "s"(fa0.w), "s"(fb0.w));
         GC_ADD(gc, visited, 1);
         if (!__any((tp0 < best0) | (tp1 < best1))) continue;  // wave-uniform
         GC_ADD(gc, entered, 1);
