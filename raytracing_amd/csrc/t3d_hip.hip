@@ -2316,9 +2316,16 @@ static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int nro
 #define T3D_LAUNCH_LEVEL(L0, W, P, GRID, BLOCK)                                                                                   \
     hipLaunchKernelGGL((k_level<L0, W, P>), dim3(GRID), dim3(BLOCK), 0, ls, c->sc, planes, pfirst, uv, sph, rp, d, in, outq, w.pool, \
                        c->d_cnt, out)
+            // Level 0 is launched with up to four times as many waves as the device holds at once (trace_blocks_for); a
+            // deeper level with as many as it holds, every wave walking its shard's queue in strides: alone on the device
+            // such a launch takes as long as the larger one, and when other frames are in flight on other streams their
+            // kernels get the slots its finished waves leave (with three frames in flight 0.40 -> 0.37 ms per frame;
+            // 75 % of the resident count is slower alone, 200 % and more lose the overlap).
+            const int grid_0 = grid_n * T3D_WAVES;
+            const int grid_w = std::min(grid_0, (rp.resident_waves + T3D_SHARDS - 1) / T3D_SHARDS * T3D_SHARDS);
             if (!single) {
-                if (d == 0) { if (pairs) T3D_LAUNCH_LEVEL(true, 1, true, grid_n * T3D_WAVES, 64); else T3D_LAUNCH_LEVEL(true, 1, false, grid_n * T3D_WAVES, 64); }
-                else        { if (pairs) T3D_LAUNCH_LEVEL(false, 1, true, grid_n * T3D_WAVES, 64); else T3D_LAUNCH_LEVEL(false, 1, false, grid_n * T3D_WAVES, 64); }
+                if (d == 0) { if (pairs) T3D_LAUNCH_LEVEL(true, 1, true, grid_0, 64); else T3D_LAUNCH_LEVEL(true, 1, false, grid_0, 64); }
+                else        { if (pairs) T3D_LAUNCH_LEVEL(false, 1, true, grid_w, 64); else T3D_LAUNCH_LEVEL(false, 1, false, grid_w, 64); }
             } else {
                 if (d == 0) { if (pairs) T3D_LAUNCH_LEVEL(true, T3D_WAVES, true, grid_n, T3D_BLOCK); else T3D_LAUNCH_LEVEL(true, T3D_WAVES, false, grid_n, T3D_BLOCK); }
                 else        { if (pairs) T3D_LAUNCH_LEVEL(false, T3D_WAVES, true, grid_n, T3D_BLOCK); else T3D_LAUNCH_LEVEL(false, T3D_WAVES, false, grid_n, T3D_BLOCK); }
