@@ -660,10 +660,9 @@ struct ShadowRay {
     V3 P, N, Ld, start;
     float rough, dist2, strength;
 };
-__device__ __forceinline__ ShadowRay shadow_ray(const DevScene& sc, float4 ra, float4 rb, int l) {
+__device__ __forceinline__ ShadowRay shadow_ray(const DevLight lt, float4 ra, float4 rb) {
     ShadowRay s;
     s.P = mk(ra.x, ra.y, ra.z); s.N = mk(rb.x, rb.y, rb.z); s.rough = ra.w;
-    const DevLight lt = sc.lights[l];
     const V3 to = mk(lt.x - s.P.x, lt.y - s.P.y, lt.z - s.P.z);
     s.dist2 = dot(to, to);
     s.Ld = to * __builtin_amdgcn_rsqf(s.dist2);
@@ -671,6 +670,7 @@ __device__ __forceinline__ ShadowRay shadow_ray(const DevScene& sc, float4 ra, f
     s.strength = lt.strength;
     return s;
 }
+__device__ __forceinline__ ShadowRay shadow_ray(const DevScene& sc, float4 ra, float4 rb, int l) { return shadow_ray(sc.lights[l], ra, rb); }
 // The part of the light term that does not depend on what the shadow ray hits: diffuse and specular response of the
 // surface to the light's direction (T3DR.py:850-857, 880).  Where it is zero -- the surface faces away from the light
 // and shows no highlight to the camera -- the term is zero whatever the visibility, and the ray need not be traced.
@@ -873,7 +873,7 @@ struct PairList {
 // reserves its node and ray slots with ONE atomic per counter: nodes of ray 0 of every lane in lane order, then those of
 // ray 1; child rays as (transmitted, reflected) of ray 0, then of ray 1.
 template <bool LEVEL0, int RING, bool PAIRS = false, bool ONE = true, int NR = 1>
-__device__ __forceinline__ void process_rays(const DevScene& sc, const DevSphere* __restrict__ spheres, const RenderParams& rp,
+__device__ __forceinline__ void process_rays(const DevScene& sc, const DevLight* __restrict__ lights, const RenderParams& rp,
                                              const WaveCtx& wc, const RayIn (&in)[NR], const Hit (&h)[NR], RayRec* __restrict__ rays_out,
                                              const NodePool& pool, Counters* cnt, const TraceOut& out, float4* ring_a,
                                              float4* ring_b, int& ring_nodes, PairList* pl = nullptr) {
@@ -948,7 +948,9 @@ __device__ __forceinline__ void process_rays(const DevScene& sc, const DevSphere
             const float4 ra = make_float4(oc[r].P.x, oc[r].P.y, oc[r].P.z, oc[r].rough), rb = make_float4(oc[r].N.x, oc[r].N.y, oc[r].N.z, 0.0f);
             pair_pos[r] = pairs_total;
             for (int l = 0; l < wc.L; ++l) {
-                const bool lv = oc[r].shaded && !shadow_dead(sc, shadow_ray(sc, ra, rb, l));
+                // lights: the light array as a kernel argument of its own, so that this wave-uniform read goes through the
+                // scalar cache (through the pointer in the scene structure it would be a vector load, waited for per light)
+                const bool lv = oc[r].shaded && !shadow_dead(sc, shadow_ray(lights[l], ra, rb));
                 const unsigned long long m = __ballot(lv);
                 pair_pos[r] += __popcll(m & wc.lt_mask);
                 pairs_total += __popcll(m);
@@ -1099,7 +1101,7 @@ __device__ __forceinline__ void load_ray(const DevScene& sc, const RenderParams&
 // per counter per 64 rays.
 // ------------------------------------------------------------------------------------------------
 template <bool LEVEL0, int WAVES, bool PAIRS>
-__global__ __launch_bounds__(64 * WAVES, 4) void k_level(DevScene sc, GEO_PARAMS, RenderParams rp, int level,
+__global__ __launch_bounds__(64 * WAVES, 4) void k_level(DevScene sc, GEO_PARAMS, const DevLight* __restrict__ light_rows, RenderParams rp, int level,
                                                       const RayRec* __restrict__ rays_in, RayRec* __restrict__ rays_out,
                                                       NodePool pool, Counters* cnt, TraceOut out) {
     constexpr int RING = T3D_RING;
@@ -1199,7 +1201,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_level(DevScene sc, GEO_PARAMS
                 if (g1.t < 0.0f) h[1] = g1;
             }
 #endif
-            process_rays<LEVEL0, RING, PAIRS, ONE, 2>(sc, spheres, rp, wc, in, h, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes, &pl);
+            process_rays<LEVEL0, RING, PAIRS, ONE, 2>(sc, light_rows, rp, wc, in, h, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes, &pl);
             chunk += chunk_step;
             // the ring is private to this wave; LDS operations of one wave complete in order, the fences
             // only stop the compiler from moving the next round's reads above these writes
@@ -1350,7 +1352,7 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_bvh_process(DevScene sc, const De
             const uint2 r = hits[in[0].i];
             h[0].t = __uint_as_float(r.x & 0x7fffffffu); h[0].back = (int)(r.x >> 31); h[0].prim = (int)r.y;
         }
-        process_rays<LEVEL0, 0>(sc, spheres, rp, wc, in, h, rays_out, pool, cnt, out, src_a, src_b, unused);
+        process_rays<LEVEL0, 0>(sc, sc.lights, rp, wc, in, h, rays_out, pool, cnt, out, src_a, src_b, unused);
     }
 }
 
@@ -2314,7 +2316,7 @@ static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int nro
             // waves of k_level never talk to each other: one wave per workgroup, so that a finished wave's slot is free at
             // once instead of when the slowest of four is done (1.5 % on the benchmark frame)
 #define T3D_LAUNCH_LEVEL(L0, W, P, GRID, BLOCK)                                                                                   \
-    hipLaunchKernelGGL((k_level<L0, W, P>), dim3(GRID), dim3(BLOCK), 0, ls, c->sc, planes, pfirst, uv, sph, rp, d, in, outq, w.pool, \
+    hipLaunchKernelGGL((k_level<L0, W, P>), dim3(GRID), dim3(BLOCK), 0, ls, c->sc, planes, pfirst, uv, sph, c->sc.lights, rp, d, in, outq, w.pool, \
                        c->d_cnt, out)
             // Level 0 is launched with up to four times as many waves as the device holds at once (trace_blocks_for); a
             // deeper level with as many as it holds, every wave walking its shard's queue in strides: alone on the device
