@@ -1173,14 +1173,6 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_level(DevScene sc, GEO_PARAMS
             const ShadowRay s1 = shadow_ray(sc, ring_a[nd1 % RING], rb1, l1);
             Hit h0, h1;
             closest_hit2<false, true>(GEO_ARGS, sc.geo, s0.start, s0.Ld, s1.start, s1.Ld, true, false, false, h0, h1, gcp_s);
-#if T3D_EXP == 1
-            {   // experiment: the shadow closest hit a second time
-                Hit g0, g1;
-                closest_hit2<false, true>(GEO_ARGS, sc.geo, madd(s0.start, s0.Ld, 1e-30f * h0.t), s0.Ld, madd(s1.start, s1.Ld, 1e-30f * h1.t), s1.Ld, true, false, false, g0, g1);
-                if (g0.t < 0.0f) h0 = g0;
-                if (g1.t < 0.0f) h1 = g1;
-            }
-#endif
             const float I0 = shadow_intensity(sc, spheres, s0, h0), I1 = shadow_intensity(sc, spheres, s1, h1);
             if (run0) pool.li[(wc.node_base + (size_t)__float_as_int(rb0.w)) * L + l0] = I0;
             if (run1) pool.li[(wc.node_base + (size_t)__float_as_int(rb1.w)) * L + l1] = I1;
@@ -1193,14 +1185,6 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_level(DevScene sc, GEO_PARAMS
             const bool lights = LEVEL0 ? (rp.lights != 0) : true;
             Hit h[2];  // back faces culled iff ray.ior == 1 (T3DR.py:961)
             closest_hit2<LEVEL0>(GEO_ARGS, sc.geo, in[0].o, in[0].d, in[1].o, in[1].d, lights, in[0].ior == 1.0f, in[1].ior == 1.0f, h[0], h[1], gcp_t);
-#if T3D_EXP == 2
-            {   // experiment: the trace closest hit a second time
-                Hit g0, g1;
-                closest_hit2<LEVEL0>(GEO_ARGS, sc.geo, madd(in[0].o, in[0].d, 1e-30f * h[0].t), in[0].d, madd(in[1].o, in[1].d, 1e-30f * h[1].t), in[1].d, lights, in[0].ior == 1.0f, in[1].ior == 1.0f, g0, g1);
-                if (g0.t < 0.0f) h[0] = g0;
-                if (g1.t < 0.0f) h[1] = g1;
-            }
-#endif
             process_rays<LEVEL0, RING, PAIRS, ONE, 2>(sc, light_rows, rp, wc, in, h, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes, &pl);
             chunk += chunk_step;
             // the ring is private to this wave; LDS operations of one wave complete in order, the fences
