@@ -71,9 +71,14 @@ def check_case(out, ref, frag, opt, n_lights=0):
     for k in ("rays_api", "queries") if opt["lights"] else ("rays_api",):   # lights off: the reference traces on behind emitters
         # one node more or less is one shadow ray per light more or less, and its children
         assert abs(out["stats"][k] - ref["stats"][k]) <= max(2, ref["stats"][k] // 1000) * (n_lights + 2), (k, out["stats"][k], ref["stats"][k])
+    # how far from the oracle the case was, inside the tolerances: reported so that drift shows from one run to the next
+    return {"pixels": int(diff.size), "differ": int((diff > 0).sum()), "beyond_1_lsb": int((diff > 1).sum()), "max_radiance_error": float(err.max()),
+            "ids_differ": int((out["prim"] != ref["prim"]).any(axis=2).sum())}
 
 
-def run_cases(first, count, report=print, big=False, untimed=False):
+def run_cases(first, count, report=print, big=False, untimed=False, drift=None):
+    """drift: a dict that collects, over all cases and both paths, how many pixels differed from the oracle at all, by more
+    than 1 LSB, in their primary ids, and the largest radiance error."""
     from oracle import oracle
     from raytracing_amd import _native
     from raytracing_amd.flatten import flatten_scene
@@ -94,7 +99,12 @@ def run_cases(first, count, report=print, big=False, untimed=False):
                 c.upload(flat)
                 out = c.render_rows(opt, seed=seed, want_radiance=True, want_primary=True)
                 try:
-                    check_case(out, ref, frag, opt, len(flat.light_strength))
+                    d = check_case(out, ref, frag, opt, len(flat.light_strength))
+                    counts["drift_" + a] = d
+                    if drift is not None:
+                        for k in ("pixels", "differ", "beyond_1_lsb", "ids_differ"):
+                            drift[k] = drift.get(k, 0) + d[k]
+                        drift["max_radiance_error"] = max(drift.get("max_radiance_error", 0.0), d["max_radiance_error"])
                     # the two paths evaluate the interior test differently (two in-plane coordinates against three):
                     # they too may part ways at an edge, by as little
                     # any part of the frame -- a block of rows, every n-th row -- is the same pixels, exactly
@@ -133,7 +143,10 @@ def run_cases(first, count, report=print, big=False, untimed=False):
                     raise AssertionError(f"seed {seed} {a}: {opt} tris {flat.n_tris} spheres {flat.n_spheres} "
                                          f"lights {len(flat.light_strength)}: {str(e)[:300]}") from None
             report(f"seed {seed}: {opt['width']}x{opt['height']} b{opt['bounces']} s{opt['samples']} tris {flat.n_tris} spheres {flat.n_spheres} "
-                   f"lights {len(flat.light_strength)} queries {ref['stats']['queries']} ok")
+                   f"lights {len(flat.light_strength)} queries {ref['stats']['queries']} ok; pixels that differ (brute / lbvh) "
+                   f"{counts['drift_brute']['differ']} / {counts['drift_lbvh']['differ']}, by more than 1 LSB "
+                   f"{counts['drift_brute']['beyond_1_lsb']} / {counts['drift_lbvh']['beyond_1_lsb']}, max radiance error "
+                   f"{max(counts['drift_brute']['max_radiance_error'], counts['drift_lbvh']['max_radiance_error']):.4f}")
     finally:
         for c in ctxs.values():
             c.close()
@@ -144,11 +157,13 @@ def main():
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 24
     big = "big" in sys.argv[3:]              # meshes of hundreds of small triangles: deep hierarchies
     untimed = "untimed" in sys.argv[3:]      # per-kernel timing off
+    drift = {}
     try:
-        run_cases(first, count, report=lambda line: print(line, flush=True), big=big, untimed=untimed)
+        run_cases(first, count, report=lambda line: print(line, flush=True), big=big, untimed=untimed, drift=drift)
     except AssertionError as e:
         print("FAILED:", e)
         sys.exit(1)
+    print("drift over all cases and both paths:", drift)
 
 
 if __name__ == "__main__":
