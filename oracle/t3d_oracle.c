@@ -313,10 +313,16 @@ int t3do_enters_aabb(const double* start, const double* dir, const double* bmin,
 typedef struct { int hit; V3 point; double t; V3 normal; int direction; } Hit;
 
 /* Photon.getSphereCollision T3DR.py:572-598 with Ray.getTSphere T3DE.py:145-163 */
-static Hit sphere_collision(const Ray* ray, V3 center, double radius, int is_light, int backCull) {
+static Hit sphere_collision(Ctx* c, const Ray* ray, V3 center, double radius, int is_light, int backCull) {
     Hit h; memset(&h, 0, sizeof h);
     V3 L = vsub(ray->start, center);
     double disc = pow(vdot(L, ray->dir), 2.0) - (vdot(L, L) - pow(radius, 2.0));
+    if (c && radius > 0) {
+        /* fragility (test aid): how far the ray passes from the sphere's silhouette, relative to the radius squared --
+         * a ray that grazes the sphere may hit it in one precision and miss it in another, like a ray on a triangle's edge */
+        double r = fabs(disc) / (radius * radius);
+        if (r < c->frag) c->frag = r;
+    }
     if (disc < 0) return h;
     double t1 = (vdot(L, ray->dir) * -1) - sqrt(disc);
     double t2 = (vdot(L, ray->dir) * -1) + sqrt(disc);
@@ -414,7 +420,7 @@ static Collision first_collision(Ctx* c, const Ray* ray, int lights, int backCul
         if (ty == T3D_OBJ_SPHERE || (lights && ty == T3D_OBJ_LIGHT)) {
             c->st.sphere_tests++;
             V3 ctr = v3(s->obj_center[3 * o], s->obj_center[3 * o + 1], s->obj_center[3 * o + 2]);
-            Hit h = sphere_collision(ray, ctr, s->obj_radius[o], ty == T3D_OBJ_LIGHT, backCull);
+            Hit h = sphere_collision(c, ray, ctr, s->obj_radius[o], ty == T3D_OBJ_LIGHT, backCull);
             if (h.hit && (best.obj < 0 || h.t < best.t)) {
                 best.obj = o; best.point = h.point; best.t = h.t; best.normal = h.normal;
                 best.direction = h.direction;
@@ -771,7 +777,7 @@ int t3do_render_rows(const t3d_scene_desc* s, const t3d_opts* o, int row0, int n
 }
 
 /* Primary-hit fragility only: for every pixel, the smallest relative margin of any inside test
- * (and of the t >= 0 cut) met by the PRIMARY ray.  Pixels whose margin is below a float32-sized
+ * (and of the t >= 0 cut, and of the silhouette of any sphere) met by the PRIMARY ray.  Pixels whose margin is below a float32-sized
  * threshold are the "edge-tie pixels" where a float32 tracer may legitimately pick another face. */
 int t3do_primary_fragility(const t3d_scene_desc* s, const t3d_opts* o, int row0, int nrows, double* frag_out) {
     if (!s || !o || !frag_out) return T3D_E_INVALID;
@@ -823,7 +829,7 @@ int t3do_sphere_collision(const double* start, const double* dir, const double* 
                           int is_light, int backCull, double* t, double* point, double* normal,
                           int32_t* direction) {
     Ray r = make_ray(v3(start[0], start[1], start[2]), v3(dir[0], dir[1], dir[2]), 1, -1);
-    Hit h = sphere_collision(&r, v3(center[0], center[1], center[2]), radius, is_light, backCull);
+    Hit h = sphere_collision(NULL, &r, v3(center[0], center[1], center[2]), radius, is_light, backCull);
     if (!h.hit) return 0;
     *t = h.t; *direction = h.direction;
     point[0] = h.point.x; point[1] = h.point.y; point[2] = h.point.z;

@@ -178,7 +178,7 @@ def test_closest_hits_through_lbvh(lbvh_ctx, oracle_mod):
 
 
 def test_large_scene_properties(gpu_ctx, oracle_mod):
-    """200 000 triangles + 2 000 spheres, 960x540: determinism, partition independence, oracle on a few rows."""
+    """200 000 triangles + 2 000 spheres, 960x540: determinism, partition independence, oracle on every 20th row."""
     flat = _soup(100_000, 224, 2000)
     gpu_ctx.set_accel("auto")
     gpu_ctx.upload(flat)
@@ -194,9 +194,9 @@ def test_large_scene_properties(gpu_ctx, oracle_mod):
         frame[r::4] = o["bgr"]
         rays += o["stats"]["rays_api"]
     assert np.array_equal(frame, full["bgr"]) and rays == full["stats"]["rays_api"]
-    step = 90
-    ref = oracle_mod.render(flat, opt, seed=0, row0=0, row_stride=step, want_radiance=False)
-    frag = oracle_mod.primary_fragility(flat, dict(opt), row0=0, row_stride=step)
+    step = 20   # 27 rows, spread over the host's threads
+    from conftest import oracle_rows_threaded
+    ref, frag = oracle_rows_threaded(oracle_mod, flat, opt, 0, range(0, H, step))
     sub = dict(bgr=full["bgr"][::step], prim=full["prim"][::step], prim_t=full["prim_t"][::step], radiance=None, stats=ref["stats"])
     check_against_oracle(sub, ref, frag)
 
@@ -214,8 +214,8 @@ def _frame_properties(ctx, oracle_mod, flat, opt, row_step, parts=8):
         frame[r::parts] = o["bgr"]
         rays += o["stats"]["rays_api"]
     assert np.array_equal(frame, full["bgr"]) and rays == full["stats"]["rays_api"]
-    ref = oracle_mod.render(flat, opt, seed=0, row0=0, row_stride=row_step, want_radiance=False)
-    frag = oracle_mod.primary_fragility(flat, dict(opt), row0=0, row_stride=row_step)
+    from conftest import oracle_rows_threaded
+    ref, frag = oracle_rows_threaded(oracle_mod, flat, opt, 0, range(0, H, row_step))   # the rows spread over the host's threads
     sub = dict(bgr=full["bgr"][::row_step], prim=full["prim"][::row_step], prim_t=full["prim_t"][::row_step], radiance=None,
                stats=ref["stats"])
     check_against_oracle(sub, ref, frag)
@@ -228,14 +228,14 @@ def test_suzanne_4k_full_size(gpu_ctx, oracle_mod):
     flat, opt = get_flat_workload("suzanne_4k_b4")
     gpu_ctx.set_accel("auto")
     gpu_ctx.upload(flat)
-    full = _frame_properties(gpu_ctx, oracle_mod, flat, opt, row_step=216)
+    full = _frame_properties(gpu_ctx, oracle_mod, flat, opt, row_step=8)    # 270 rows against the oracle
     assert full["stats"]["aabb_tests"] > 0
 
 
 def test_synthetic_1m_4k_full_size(gpu_ctx, oracle_mod):
     """1 000 000 triangles + 10 000 spheres, 4 lights, 3840x2160, 2 bounces (the large-scene benchmark workload): a
     20-level hierarchy over quantised records with colliding sort keys.  Determinism, independence of the row
-    partition, and the oracle on eight rows spread over the frame (each a full closest-hit search through the
+    partition, and the oracle on sixteen rows spread over the frame (each a full closest-hit search through the
     reference's own per-mesh hierarchy in float64)."""
     from conftest import oracle_rows_threaded
     from raytracing_amd.workloads import get_flat_workload
@@ -256,8 +256,8 @@ def test_synthetic_1m_4k_full_size(gpu_ctx, oracle_mod):
         frame[r::4] = o["bgr"]
         rays += o["stats"]["rays_api"]
     assert np.array_equal(frame, full["bgr"]) and rays == st["rays_api"]
-    rows = [7, 301, 611, 905, 1203, 1511, 1799, 2152]
-    ref, frag = oracle_rows_threaded(oracle_mod, flat, opt, 0, rows, threads=8)
+    rows = [7, 151, 301, 455, 611, 760, 905, 1051, 1203, 1360, 1511, 1655, 1799, 1970, 2152, 2159]
+    ref, frag = oracle_rows_threaded(oracle_mod, flat, opt, 0, rows, threads=16)
     sub = dict(bgr=full["bgr"][rows], prim=full["prim"][rows], prim_t=full["prim_t"][rows], radiance=None, stats=ref["stats"])
     # the counters of the sub-frame are the oracle's own: what is compared is pixels, ids and distances
     check_against_oracle(sub, ref, frag)
@@ -269,7 +269,7 @@ def test_cornell2_8k_full_size(gpu_ctx, oracle_mod):
     flat, opt = get_flat_workload("cornell2_8k_b8")
     gpu_ctx.set_accel("auto")
     gpu_ctx.upload(flat)
-    _frame_properties(gpu_ctx, oracle_mod, flat, opt, row_step=432)
+    _frame_properties(gpu_ctx, oracle_mod, flat, opt, row_step=24)     # 180 rows against the oracle
 
 
 def test_deep_traversal_stack(gpu_ctx, oracle_mod):

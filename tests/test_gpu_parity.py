@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 LSB_OK_FRACTION = 0.999
 RADIANCE_TOL = 0.05
-EDGE_TIE_MARGIN = 1e-5
+EDGE_TIE_MARGIN = 1e-5   # relative margin of a primary ray from a triangle edge or a sphere silhouette below which float32 may pick another primitive
 
 
 def check_against_oracle(out, ref, frag=None, lights=True):
