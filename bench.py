@@ -263,7 +263,11 @@ def main():
                          "flops_per_launch": flops / max(1, last["n_k_level"]),
                          "queries_per_launch": last_traced / max(1, last["n_k_level"]),
                          "frame_device_ms": round(last["ms_device"], 4), "resolve_ms": round(last["ms_resolve"], 4),
-                         "measured_on": "one frame alone on the device, after the timed steps"},
+                         "measured_on": "one frame alone on the device, after the timed steps",
+                         # the same launches priced by the queries the reference counts (the shadow rays answered without a ray
+                         # included): comparable with figures that predate the culling of those rays
+                         "frac_in_reference_queries": round(last["queries"] * (FLOP_PER_TRI_TEST * T + FLOP_PER_SPHERE_TEST * S)
+                                                            / level_s / 1e12 / FP32_VALU_PEAK_TFLOPS, 4) if level_s > 0 else None},
             # the whole pipeline as timed: every flop of the frame over the time a frame takes with F in flight
             "pipeline": {"frames_in_flight": F, "frame_latency_ms": round(last["ms_device"], 4),
                          # this rank's share of one frame with nothing else on the device, as a rate
