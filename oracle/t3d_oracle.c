@@ -355,6 +355,15 @@ static Hit face_collision(Ctx* c, const Ray* ray, V3 a, V3 b, V3 cc) {
     double dn = vdot(ray->dir, normal);
     if (-0.000001 < dn && dn < 0.000001) return h;
     double t = (vdot(normal, a) - vdot(normal, ray->start)) / vdot(normal, ray->dir);
+    if (c) {
+        /* fragility (test aid): a ray that starts within a few float32 steps of the face's plane (a child ray that leaves its
+         * surface at a grazing angle, seen from that surface's plane or from a face coplanar with it) is on either side of the
+         * t >= 0 cut depending on how its start point was rounded */
+        double dist = fabs(vdot(normal, ray->start) - vdot(normal, a)) / sqrt(vdot(normal, normal));
+        double mag = fabs(ray->start.x) > fabs(ray->start.y) ? fabs(ray->start.x) : fabs(ray->start.y);
+        if (fabs(ray->start.z) > mag) mag = fabs(ray->start.z);
+        if (dist < 4e-6 * (mag > 1 ? mag : 1)) c->frag = 0;
+    }
     if (t < 0) {
         if (c && t > -1e-4) c->frag = 0; /* hit distance on the t >= 0 boundary */
         return h;
@@ -738,10 +747,10 @@ int t3do_render_rows(const t3d_scene_desc* s, const t3d_opts* o, int row0, int n
             Ray ray = camera_ray(s, o, x, py);
             c.kx = (uint32_t)x; c.ky = (uint32_t)py;
             size_t pix = (size_t)y * W + x;
+            c.frag = INFINITY;
             for (int k = 0; k < nsamp; k++) {
                 c.ks = (uint32_t)k;
                 uint64_t q0 = c.st.queries;
-                c.frag = INFINITY;
                 Node* tree = trace(&c, &ray, o->bounces, o->lights, 1);
                 (void)q0;
                 c.st.rays_api++;
@@ -758,7 +767,7 @@ int t3do_render_rows(const t3d_scene_desc* s, const t3d_opts* o, int row0, int n
                 samples[k] = compute_color(&c, tree);
                 free_tree(tree);
             }
-            if (fragility_out) fragility_out[pix] = c.frag; /* note: covers every ray of the last sample */
+            if (fragility_out) fragility_out[pix] = c.frag; /* smallest margin met by any ray of any sample of the pixel */
             /* RGB.mean T3DE.py:401-415 */
             double tr = 0, tg = 0, tb = 0;
             for (int k = 0; k < nsamp; k++) { tr += samples[k].r; tg += samples[k].g; tb += samples[k].b; }

@@ -759,5 +759,7 @@ def test_random_scenes_on_both_paths(oracle_mod):
     assert len(lines) == 55
     # inside the tolerances, but worth seeing from run to run (pytest -s, or the line of a failing run)
     print("random scenes, both paths: of", drift["pixels"], "pixels", drift["differ"], "differ from the oracle,", drift["beyond_1_lsb"],
-          "by more than 1 LSB,", drift["ids_differ"], "in their primary ids; largest radiance error", round(drift["max_radiance_error"], 4))
+          "by more than 1 LSB,", drift["ids_differ"], "in their primary ids; largest radiance error", round(drift["max_radiance_error"], 4),
+          ";", drift["fragile"], "pixels had a ray on a decision boundary as far as float32 can tell and were set aside")
+    assert drift["fragile"] <= drift["pixels"] // 100
     assert drift["beyond_1_lsb"] <= 55 and drift["differ"] <= drift["pixels"] // 500

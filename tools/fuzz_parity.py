@@ -1,6 +1,7 @@
 """Random scenes and options through both closest-hit paths of the HIP library against the CPU oracle.
-usage: fuzz_parity.py [first_seed] [count] [big] [untimed]; prints one line per case and exits non-zero on the first disagreement
-beyond the tolerances of tests/test_gpu_parity.py."""
+usage: fuzz_parity.py [first_seed] [count] [big] [untimed] [deep]; prints one line per case and exits non-zero on the first
+disagreement beyond the tolerances of tests/test_gpu_parity.py.  deep: 6 to 12 bounces instead of 0 to 5.  With
+T3D_MEM_BUDGET_MB=1 in the environment the library cuts every frame into bands."""
 import os
 import sys
 
@@ -10,7 +11,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 
 
-def random_scene(seed, big=False):
+def random_scene(seed, big=False, deep=False):
     from raytracing_amd.scene import RGB, Camera, Euler, Light, Material, Mesh, Object, Scale, Scene, Shader, Sphere, Vec3
     rng = np.random.default_rng(seed)
     s = Scene()
@@ -50,7 +51,7 @@ def random_scene(seed, big=False):
         ball.material = Material(ior=float(rng.choice([1.0, 1.33, 1.5])))
     for l in range(int(rng.integers(0, 4))):
         Light(s, name=f"light{l}", position=Vec3(*(float(v) for v in rng.uniform(-3, 3, 3) + [0, 3, 0])), strength=float(rng.uniform(0.3, 1.5)))
-    opt = dict(width=int(rng.integers(8, 90)), height=int(rng.integers(6, 60)), bounces=int(rng.integers(0, 6)),
+    opt = dict(width=int(rng.integers(8, 90)), height=int(rng.integers(6, 60)), bounces=int(rng.integers(6, 13)) if deep else int(rng.integers(0, 6)),
                samples=int(rng.integers(1, 4)), ambient=tuple(int(v) for v in rng.integers(0, 60, 3)), lights=bool(rng.random() < 0.85))
     return s, opt
 
@@ -62,10 +63,13 @@ def check_case(out, ref, frag, opt, n_lights=0):
     from edges must be identical."""
     from test_gpu_parity import EDGE_TIE_MARGIN, RADIANCE_TOL
     allowed = max(1, out["bgr"].shape[0] * out["bgr"].shape[1] // 1000)
+    # pixels in whose trees some ray of some sample sits on a decision boundary as far as float32 can tell (a start point
+    # in the plane of a face, a hit at distance zero) are reported by the oracle with a margin of zero and set aside
+    sturdy = ref["fragility"] > 0
     diff = np.abs(out["bgr"].astype(int) - ref["bgr"].astype(int)).max(axis=2)
-    assert (diff > 1).sum() <= allowed, f"{(diff > 1).sum()} pixels differ by more than 1 LSB"
+    assert ((diff > 1) & sturdy).sum() <= allowed, f"{((diff > 1) & sturdy).sum()} pixels differ by more than 1 LSB"
     err = np.abs(out["radiance"].astype(np.float64) - ref["radiance"]).max(axis=2)
-    assert (err > RADIANCE_TOL).sum() <= allowed, f"{(err > RADIANCE_TOL).sum()} pixels with a radiance error, max {err.max()}"
+    assert ((err > RADIANCE_TOL) & sturdy).sum() <= allowed, f"{((err > RADIANCE_TOL) & sturdy).sum()} pixels with a radiance error, max {err.max()}"
     mism = (out["prim"] != ref["prim"]).any(axis=2) & (frag > EDGE_TIE_MARGIN)
     assert mism.sum() == 0, f"{mism.sum()} primary-hit id mismatches away from triangle edges"
     for k in ("rays_api", "queries") if opt["lights"] else ("rays_api",):   # lights off: the reference traces on behind emitters
@@ -73,10 +77,10 @@ def check_case(out, ref, frag, opt, n_lights=0):
         assert abs(out["stats"][k] - ref["stats"][k]) <= max(2, ref["stats"][k] // 1000) * (n_lights + 2), (k, out["stats"][k], ref["stats"][k])
     # how far from the oracle the case was, inside the tolerances: reported so that drift shows from one run to the next
     return {"pixels": int(diff.size), "differ": int((diff > 0).sum()), "beyond_1_lsb": int((diff > 1).sum()), "max_radiance_error": float(err.max()),
-            "ids_differ": int((out["prim"] != ref["prim"]).any(axis=2).sum())}
+            "ids_differ": int((out["prim"] != ref["prim"]).any(axis=2).sum()), "fragile": int((~sturdy).sum())}
 
 
-def run_cases(first, count, report=print, big=False, untimed=False, drift=None):
+def run_cases(first, count, report=print, big=False, untimed=False, drift=None, deep=False):
     """drift: a dict that collects, over all cases and both paths, how many pixels differed from the oracle at all, by more
     than 1 LSB, in their primary ids, and the largest radiance error."""
     from oracle import oracle
@@ -90,9 +94,9 @@ def run_cases(first, count, report=print, big=False, untimed=False, drift=None):
             if untimed:      # no per-kernel events: LBVH scenes run their shadow kernels on a stream of their own, overlapping the next level
                 c.set_timing(False)
         for seed in range(first, first + count):
-            scene, opt = random_scene(seed, big)
+            scene, opt = random_scene(seed, big, deep)
             flat = flatten_scene(scene)
-            ref = oracle.render(flat, opt, seed=seed)
+            ref = oracle.render(flat, opt, seed=seed, want_fragility=True)
             frag = oracle.primary_fragility(flat, opt)
             counts = {}
             for a, c in ctxs.items():
@@ -102,7 +106,7 @@ def run_cases(first, count, report=print, big=False, untimed=False, drift=None):
                     d = check_case(out, ref, frag, opt, len(flat.light_strength))
                     counts["drift_" + a] = d
                     if drift is not None:
-                        for k in ("pixels", "differ", "beyond_1_lsb", "ids_differ"):
+                        for k in ("pixels", "differ", "beyond_1_lsb", "ids_differ", "fragile"):
                             drift[k] = drift.get(k, 0) + d[k]
                         drift["max_radiance_error"] = max(drift.get("max_radiance_error", 0.0), d["max_radiance_error"])
                     # the two paths evaluate the interior test differently (two in-plane coordinates against three):
@@ -157,9 +161,10 @@ def main():
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 24
     big = "big" in sys.argv[3:]              # meshes of hundreds of small triangles: deep hierarchies
     untimed = "untimed" in sys.argv[3:]      # per-kernel timing off
+    deep = "deep" in sys.argv[3:]            # 6 to 12 bounces
     drift = {}
     try:
-        run_cases(first, count, report=lambda line: print(line, flush=True), big=big, untimed=untimed, drift=drift)
+        run_cases(first, count, report=lambda line: print(line, flush=True), big=big, untimed=untimed, drift=drift, deep=deep)
     except AssertionError as e:
         print("FAILED:", e)
         sys.exit(1)
