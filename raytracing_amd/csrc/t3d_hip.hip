@@ -1098,7 +1098,7 @@ __device__ __forceinline__ void load_ray(const DevScene& sc, const RenderParams&
 //
 // Queues are sharded T3D_SHARDS ways: wave w appends to shard w % T3D_SHARDS (own counter in its own
 // 64-byte line, own slice of the arrays) with wave64 ballot + prefix-popcount compaction and ONE atomic
-// per counter per 64 rays.
+// per counter per round of 128 rays (k_bvh_process: per 64).
 // ------------------------------------------------------------------------------------------------
 template <bool LEVEL0, int WAVES, bool PAIRS>
 __global__ __launch_bounds__(64 * WAVES, 4) void k_level(DevScene sc, GEO_PARAMS, const DevLight* __restrict__ light_rows, RenderParams rp, int level,
@@ -1215,7 +1215,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_level(DevScene sc, GEO_PARAMS
 // ------------------------------------------------------------------------------------------------
 // LBVH path: one tree level = three launches.
 //   k_bvh_trace    closest hit of every ray of the level -> hits[]
-//   k_bvh_process  classification, child rays, node records (process_ray) from the stored hits; the shading
+//   k_bvh_process  classification, child rays, node records (process_rays) from the stored hits; the shading
 //                  inputs of every new node (hit point, normal, roughness) go to src_a / src_b
 //   k_bvh_shadow   closest hit of the shadow ray of every (node, light) pair -> li[node][light]
 // Rays of one wave need very different numbers of traversal steps, and a wave lasts as long as its slowest lane.
