@@ -374,7 +374,11 @@ __device__ __forceinline__ bool ray_meets_scene_box(const DevGeo& geo, V3 o, V3 
 
 template <bool BOX_FIRST = false, bool NO_CULL = false>
 __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0, V3 d0, V3 o1, V3 d1,
-                                             bool lights, bool back_cull0, bool back_cull1, Hit& out0, Hit& out1, GroupCount* gc = nullptr) {
+                                             bool lights, bool back_cull0, bool back_cull1, Hit& out0, Hit& out1, GroupCount* gc = nullptr,
+                                             float bound0 = __builtin_inff(), float bound1 = __builtin_inff()) {
+    // bound0 / bound1: only hits nearer than this count (non-negative; +inf: no bound).  The closest hit below the bound is
+    // the closest hit, and a plane group that no ray of the wave meets below its bound is skipped like one that no ray
+    // meets below its best distance.
     GC_ADD(gc, calls, 1);
     const uint32_t INF_BITS = 0x7f800000u;
     const f2 ox = {o0.x, o1.x}, oy = {o0.y, o1.y}, oz = {o0.z, o1.z};
@@ -383,7 +387,7 @@ __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0
     if constexpr (BOX_FIRST) any_inside = __any((int)ray_meets_scene_box(geo, o0, d0) | (int)ray_meets_scene_box(geo, o1, d1));
     const f2 cull = {back_cull0 ? 0.0f : __builtin_inff(), back_cull1 ? 0.0f : __builtin_inff()};
     const f2 big = splat(0x1p126f);
-    uint32_t best0 = INF_BITS, best1 = INF_BITS;
+    uint32_t best0 = __float_as_uint(bound0), best1 = __float_as_uint(bound1);
     float A0 = 0.0f, A1 = 0.0f;
     int bg0 = 0, bg1 = 0;
     int prim0 = -1, prim1 = -1, back0 = 0, back1 = 0;
@@ -391,8 +395,8 @@ __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0
     plane_groups<0, NO_CULL>(planes, plane_first, tri_uv, 0, geo.axis_end[0], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1, gc);
     plane_groups<1, NO_CULL>(planes, plane_first, tri_uv, geo.axis_end[0], geo.axis_end[1], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1, gc);
     plane_groups<2, NO_CULL>(planes, plane_first, tri_uv, geo.axis_end[1], geo.axis_end[2], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1, gc);
-    if (best0 < INF_BITS) prim0 = first_hit_of_group(plane_first, bg0, A0);
-    if (best1 < INF_BITS) prim1 = first_hit_of_group(plane_first, bg1, A1);
+    if (A0 >= 1.0f) prim0 = first_hit_of_group(plane_first, bg0, A0);   // some group was hit (its hit bits are kept with it)
+    if (A1 >= 1.0f) prim1 = first_hit_of_group(plane_first, bg1, A1);
     // Spheres and lights.  getSphereCollision (T3DR.py:572-598), Ray.getTSphere (T3DE.py:145-163).
     const int n_tris = geo.n_tris;
     for (int s = 0; s < geo.n_spheres; ++s) {
@@ -424,8 +428,8 @@ __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0
         }
     }
     }
-    out0.t = __uint_as_float(best0); out0.prim = prim0; out0.back = back0;
-    out1.t = __uint_as_float(best1); out1.prim = prim1; out1.back = back1;
+    out0.t = prim0 >= 0 ? __uint_as_float(best0) : __builtin_inff(); out0.prim = prim0; out0.back = back0;
+    out1.t = prim1 >= 0 ? __uint_as_float(best1) : __builtin_inff(); out1.prim = prim1; out1.back = back1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -659,6 +663,7 @@ __device__ __forceinline__ void camera_ray(const DevCamera& cam, const RenderPar
 struct ShadowRay {
     V3 P, N, Ld, start;
     float rough, dist2, strength;
+    float reach;   // a little more than the distance from the ray's start to the light's position
 };
 __device__ __forceinline__ ShadowRay shadow_ray(const DevLight lt, float4 ra, float4 rb) {
     ShadowRay s;
@@ -668,6 +673,7 @@ __device__ __forceinline__ ShadowRay shadow_ray(const DevLight lt, float4 ra, fl
     s.Ld = to * __builtin_amdgcn_rsqf(s.dist2);
     s.start = madd(s.P, s.Ld, 0.2f);  // T3DR.py:840
     s.strength = lt.strength;
+    s.reach = fmaf(fmaxf(s.dist2 * __builtin_amdgcn_rsqf(s.dist2) - 0.2f, 0.0f), 1.0001f, 1e-3f);
     return s;
 }
 __device__ __forceinline__ ShadowRay shadow_ray(const DevScene& sc, float4 ra, float4 rb, int l) { return shadow_ray(sc.lights[l], ra, rb); }
@@ -1171,8 +1177,20 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_level(DevScene sc, GEO_PARAMS
             const float4 rb0 = ring_b[nd0 % RING], rb1 = ring_b[nd1 % RING];
             const ShadowRay s0 = shadow_ray(sc, ring_a[nd0 % RING], rb0, l0);
             const ShadowRay s1 = shadow_ray(sc, ring_a[nd1 % RING], rb1, l1);
+            // A shadow ray is aimed at the very position of its light: a Light's centre, the centroid of an emissive face
+            // (T3DR.py:789-816).  Unless something blocks it, the first thing it hits is that Light or that face, so the
+            // search is first bounded just behind the light's position -- the closest hit below the bound is the closest
+            // hit, and the plane groups that lie behind the light for every ray of the wave are skipped.  The reference
+            // has no distance check (T3DR.py:762-778): a ray that finds nothing up to there (a Light of radius zero, a
+            // start inside the Light) goes on through the whole scene.
             Hit h0, h1;
-            closest_hit2<false, true>(GEO_ARGS, sc.geo, s0.start, s0.Ld, s1.start, s1.Ld, true, false, false, h0, h1, gcp_s);
+            closest_hit2<false, true>(GEO_ARGS, sc.geo, s0.start, s0.Ld, s1.start, s1.Ld, true, false, false, h0, h1, gcp_s, s0.reach, s1.reach);
+            if (__any((int)(h0.prim < 0) | (int)(h1.prim < 0))) {   // wave-uniform
+                Hit g0, g1;
+                closest_hit2<false, true>(GEO_ARGS, sc.geo, s0.start, s0.Ld, s1.start, s1.Ld, true, false, false, g0, g1, gcp_s);
+                if (h0.prim < 0) h0 = g0;
+                if (h1.prim < 0) h1 = g1;
+            }
             const float I0 = shadow_intensity(sc, spheres, s0, h0), I1 = shadow_intensity(sc, spheres, s1, h1);
             if (run0) pool.li[(wc.node_base + (size_t)__float_as_int(rb0.w)) * L + l0] = I0;
             if (run1) pool.li[(wc.node_base + (size_t)__float_as_int(rb1.w)) * L + l1] = I1;
