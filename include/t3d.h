@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define T3D_ABI_VERSION 4
+#define T3D_ABI_VERSION 5
 
 enum {
     T3D_OK = 0,
@@ -316,6 +316,24 @@ int t3d_set_accel(t3d_ctx* ctx, int mode);
  * the output unfinished.  poll == NULL removes the callback.  The callback runs on the calling thread.
  */
 int t3d_set_cancel(t3d_ctx* ctx, int (*poll)(void* user), void* user);
+
+/*
+ * The image filters of the reference's Post class on 8-bit images (byte-exact).
+ *   upscale  Post.upscale (T3DR.py:1600-1614): every pixel of the [height][width][channels] image becomes a
+ *            factor x factor block of the [height * factor][width * factor][channels] output.
+ *   denoise  Post.denoise (T3DR.py:1616-1647): per channel the median -- sorted(values)[n / 2] -- of the
+ *            (2 p + 1) x (2 p + 1) window around a pixel of a 3-channel image, p = kernel_size / 2 (at most 7); the
+ *            pixels within p of the image border come out (0, 0, 0).  Input and output must not be the same buffer.
+ * The _device forms take device pointers and queue their kernel on `stream` (NULL: the context's stream) without
+ * waiting: a frame can be filtered where t3d_render_rows_device left it.  The host forms copy the image to the device
+ * and the result back (device memory allocated and freed inside the call) and return when the result is there.
+ */
+int t3d_post_upscale_device(t3d_ctx* ctx, const uint8_t* in_device, int height, int width, int channels, int factor,
+                            uint8_t* out_device, void* stream);
+int t3d_post_denoise_device(t3d_ctx* ctx, const uint8_t* in_device, int height, int width, int kernel_size,
+                            uint8_t* out_device, void* stream);
+int t3d_post_upscale(t3d_ctx* ctx, const uint8_t* in, int height, int width, int channels, int factor, uint8_t* out);
+int t3d_post_denoise(t3d_ctx* ctx, const uint8_t* in, int height, int width, int kernel_size, uint8_t* out);
 
 int t3d_abi_version(void);
 

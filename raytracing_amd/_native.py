@@ -12,13 +12,14 @@ import numpy as np
 from .flatten import FlatScene, Opts, SceneDesc, Stats, make_opts
 
 LIB_PATH = os.environ.get("T3D_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libt3d_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 SYMBOLS = ("t3d_abi_version", "t3d_device_count", "t3d_create", "t3d_destroy", "t3d_last_error",
            "t3d_upload_scene", "t3d_render_rows", "t3d_render_rows_device", "t3d_trace_pixel", "t3d_trace_ray",
            "t3d_closest_hits", "t3d_last_call_stats", "t3d_set_timing", "t3d_set_accel", "t3d_set_rounds", "t3d_set_cancel",
            "t3d_render_rows_async", "t3d_host_alloc", "t3d_host_free", "t3d_render_frame_multi",
-           "t3d_render_rows_device_static")
+           "t3d_render_rows_device_static",
+           "t3d_post_upscale_device", "t3d_post_denoise_device", "t3d_post_upscale", "t3d_post_denoise")
 
 
 class NativeError(RuntimeError):
@@ -123,6 +124,14 @@ def load():
     lib.t3d_host_free.argtypes = [C.c_void_p]
     lib.t3d_set_cancel.restype = C.c_int
     lib.t3d_set_cancel.argtypes = [C.c_void_p, CANCEL_FN, C.c_void_p]
+    lib.t3d_post_upscale_device.restype = C.c_int
+    lib.t3d_post_upscale_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.t3d_post_denoise_device.restype = C.c_int
+    lib.t3d_post_denoise_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.t3d_post_upscale.restype = C.c_int
+    lib.t3d_post_upscale.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.t3d_post_denoise.restype = C.c_int
+    lib.t3d_post_denoise.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     if lib.t3d_abi_version() != ABI_VERSION:
         raise NativeError(f"libt3d_hip.so has ABI version {lib.t3d_abi_version()}, expected {ABI_VERSION}")
     _lib = lib
@@ -291,6 +300,36 @@ class Context:
                     return 1
             self._cancel_fn = CANCEL_FN(trampoline)    # kept alive for as long as the library may call it
         self._check(self._lib.t3d_set_cancel(self._h, self._cancel_fn, None), "t3d_set_cancel")
+
+    def post_upscale(self, image, factor: int):
+        """``Post.upscale`` on the GPU: uint8 [H, W, C] -> uint8 [H * factor, W * factor, C]."""
+        img = np.ascontiguousarray(image, dtype=np.uint8)
+        if img.ndim != 3:
+            raise ValueError("image must have shape [height, width, channels]")
+        h, w, ch = img.shape
+        out = np.empty((h * max(int(factor), 0), w * max(int(factor), 0), ch), np.uint8)
+        self._check(self._lib.t3d_post_upscale(self._h, _ptr(img), h, w, ch, int(factor), _ptr(out)), "t3d_post_upscale")
+        return out
+
+    def post_denoise(self, image, kernel_size: int):
+        """``Post.denoise`` on the GPU: uint8 [H, W, 3] -> uint8 [H, W, 3] (per-channel median, zero border)."""
+        img = np.ascontiguousarray(image, dtype=np.uint8)
+        if img.ndim != 3 or img.shape[2] != 3:
+            raise ValueError("image must have shape [height, width, 3]")
+        h, w, _ = img.shape
+        out = np.empty_like(img)
+        self._check(self._lib.t3d_post_denoise(self._h, _ptr(img), h, w, int(kernel_size), _ptr(out)), "t3d_post_denoise")
+        return out
+
+    def post_upscale_device(self, in_ptr: int, height: int, width: int, channels: int, factor: int, out_ptr: int, stream: int = 0):
+        """Device-pointer form (raw addresses); queued on ``stream`` (0: the context's) without waiting."""
+        self._check(self._lib.t3d_post_upscale_device(self._h, C.c_void_p(in_ptr or None), height, width, channels, factor,
+                                                      C.c_void_p(out_ptr or None), C.c_void_p(stream or None)), "t3d_post_upscale_device")
+
+    def post_denoise_device(self, in_ptr: int, height: int, width: int, kernel_size: int, out_ptr: int, stream: int = 0):
+        """Device-pointer form (raw addresses); queued on ``stream`` (0: the context's) without waiting."""
+        self._check(self._lib.t3d_post_denoise_device(self._h, C.c_void_p(in_ptr or None), height, width, kernel_size,
+                                                      C.c_void_p(out_ptr or None), C.c_void_p(stream or None)), "t3d_post_denoise_device")
 
     def set_timing(self, per_kernel: bool):
         """Per-kernel event timing on/off (on: ms_k_level / ms_resolve filled, a few us of idle per launch)."""

@@ -45,6 +45,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -172,6 +173,7 @@ struct NodePool {
 };
 
 #include "t3d_lbvh.h"
+#include "t3d_post.h"
 
 // Queue counters.  Same-address device-scope atomics retire at roughly one per 7 ns on this chip, so one
 // counter per level would serialise the kernel: every level has T3D_SHARDS counters, each in its own
@@ -2621,6 +2623,84 @@ extern "C" int t3d_set_cancel(t3d_ctx* c, int (*poll)(void*), void* user) {
     if (!c) return T3D_E_INVALID;
     c->cancel_cb = poll; c->cancel_user = user;
     return T3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Post.upscale / Post.denoise (T3DR.py:1600-1647) on images in device memory, and on host images through it
+// ------------------------------------------------------------------------------------------------
+extern "C" int t3d_post_upscale_device(t3d_ctx* c, const uint8_t* in_device, int height, int width, int channels, int factor,
+                                       uint8_t* out_device, void* stream) {
+    if (!c) return T3D_E_INVALID;
+    if (!in_device || !out_device || height <= 0 || width <= 0 || channels <= 0 || channels > 16 || factor <= 0) { c->err = "t3d_post_upscale: bad argument"; return T3D_E_INVALID; }
+    if (height > 65535 || (long long)width * factor * channels > (1ll << 31)) { c->err = "t3d_post_upscale: output too large"; return T3D_E_CAPACITY; }
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    const unsigned row_bytes = (unsigned)width * factor * channels;
+    const int vec = (row_bytes % 16 == 0 && (uintptr_t)out_device % 16 == 0) ? 16 : (row_bytes % 4 == 0 && (uintptr_t)out_device % 4 == 0) ? 4 : 1;
+    const dim3 grid((row_bytes / vec + 255) / 256, (unsigned)height);
+    if (vec == 16) hipLaunchKernelGGL(k_post_upscale<16>, grid, dim3(256), 0, st, in_device, width, channels, factor, row_bytes, out_device);
+    else if (vec == 4) hipLaunchKernelGGL(k_post_upscale<4>, grid, dim3(256), 0, st, in_device, width, channels, factor, row_bytes, out_device);
+    else hipLaunchKernelGGL(k_post_upscale<1>, grid, dim3(256), 0, st, in_device, width, channels, factor, row_bytes, out_device);
+    HIPCHK(c, hipGetLastError());
+    return T3D_OK;
+}
+
+extern "C" int t3d_post_denoise_device(t3d_ctx* c, const uint8_t* in_device, int height, int width, int kernel_size, uint8_t* out_device,
+                                       void* stream) {
+    if (!c) return T3D_E_INVALID;
+    if (!in_device || !out_device || in_device == out_device || height <= 0 || width <= 0 || kernel_size < 0) { c->err = "t3d_post_denoise: bad argument"; return T3D_E_INVALID; }
+    const int pad = kernel_size / 2;
+    if (pad > POST_MAX_PAD) { c->err = "t3d_post_denoise: kernel size above the supported maximum (15)"; return T3D_E_CAPACITY; }
+    if ((height + POST_TILE - 1) / POST_TILE > 65535) { c->err = "t3d_post_denoise: image too tall"; return T3D_E_CAPACITY; }
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    const dim3 grid((unsigned)((width + POST_TILE - 1) / POST_TILE), (unsigned)((height + POST_TILE - 1) / POST_TILE)), block(POST_TILE, POST_TILE);
+    switch (pad) {
+#define POST_DENOISE_CASE(P) case P: hipLaunchKernelGGL(k_post_denoise<P>, grid, block, 0, st, in_device, height, width, out_device); break;
+        POST_DENOISE_CASE(1) POST_DENOISE_CASE(2) POST_DENOISE_CASE(3) POST_DENOISE_CASE(4) POST_DENOISE_CASE(5) POST_DENOISE_CASE(6) POST_DENOISE_CASE(7)
+#undef POST_DENOISE_CASE
+        default:   // a 1 x 1 window: the image itself
+            HIPCHK(c, hipMemcpyAsync(out_device, in_device, (size_t)height * width * 3, hipMemcpyDeviceToDevice, st));
+    }
+    HIPCHK(c, hipGetLastError());
+    return T3D_OK;
+}
+
+// host image in, host image out: staged through device memory of the call's own (allocated and freed here)
+static int post_on_host(t3d_ctx* c, const uint8_t* in, size_t in_bytes, uint8_t* out, size_t out_bytes,
+                        const std::function<int(const uint8_t*, uint8_t*)>& run) {
+    if (!c) return T3D_E_INVALID;
+    if (!in || !out) { c->err = "t3d_post: null image"; return T3D_E_INVALID; }
+    HIPCHK(c, hipSetDevice(c->device));
+    uint8_t* d_in = nullptr;
+    uint8_t* d_out = nullptr;
+    int rc = T3D_OK;
+    hipError_t e = hipMalloc((void**)&d_in, in_bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_out, out_bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) rc = run(d_in, d_out);
+    if (e == hipSuccess && rc == T3D_OK) e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && rc == T3D_OK) e = hipStreamSynchronize(c->stream);
+    else (void)hipStreamSynchronize(c->stream);
+    hipFree(d_in); hipFree(d_out);
+    if (e != hipSuccess) { c->err = std::string("t3d_post: ") + hipGetErrorString(e); return e == hipErrorOutOfMemory ? T3D_E_NOMEM : T3D_E_DEVICE; }
+    return rc;
+}
+
+extern "C" int t3d_post_upscale(t3d_ctx* c, const uint8_t* in, int height, int width, int channels, int factor, uint8_t* out) {
+    if (!c) return T3D_E_INVALID;
+    if (height <= 0 || width <= 0 || channels <= 0 || factor <= 0) { c->err = "t3d_post_upscale: bad argument"; return T3D_E_INVALID; }
+    const size_t nin = (size_t)height * width * channels;
+    return post_on_host(c, in, nin, out, nin * factor * factor,
+                        [&](const uint8_t* d_in, uint8_t* d_out) { return t3d_post_upscale_device(c, d_in, height, width, channels, factor, d_out, c->stream); });
+}
+
+extern "C" int t3d_post_denoise(t3d_ctx* c, const uint8_t* in, int height, int width, int kernel_size, uint8_t* out) {
+    if (!c) return T3D_E_INVALID;
+    if (height <= 0 || width <= 0) { c->err = "t3d_post_denoise: bad argument"; return T3D_E_INVALID; }
+    const size_t n = (size_t)height * width * 3;
+    return post_on_host(c, in, n, out, n,
+                        [&](const uint8_t* d_in, uint8_t* d_out) { return t3d_post_denoise_device(c, d_in, height, width, kernel_size, d_out, c->stream); });
 }
 
 // device-side outputs of the entry points that hand back host memory

@@ -1,6 +1,7 @@
 """Host-side helpers for rendered images: run-length compression of the JSON form, nearest-neighbour
 upscaling and a median filter (the ``Post`` class of the reference, T3DR.py:1550-1647).  They work on the
-finished 8-bit image and are not part of the device path; written with numpy instead of per-pixel loops."""
+finished 8-bit image; written with numpy instead of per-pixel loops.  ``upscale`` and ``denoise`` also run on the
+GPU when handed a ``context`` (a ``raytracing_amd._native.Context``): same bytes, from the library's kernels."""
 from __future__ import annotations
 
 import copy
@@ -38,13 +39,15 @@ class Post:
         return result
 
     @staticmethod
-    def upscale(imageData, factor):
+    def upscale(imageData, factor, context=None):
         """Every pixel becomes a factor x factor block (T3DR.py:1601-1613)."""
         img = np.asarray(imageData)
+        if context is not None:
+            return context.post_upscale(img, factor)
         return np.repeat(np.repeat(img, factor, axis=0), factor, axis=1).astype(np.uint8)
 
     @staticmethod
-    def denoise(imageData, kernelSize):
+    def denoise(imageData, kernelSize, context=None):
         """Per-channel median over a kernelSize x kernelSize window; the border of width kernelSize // 2 stays
         (0, 0, 0); rows of tuples, as the reference returns them (T3DR.py:1616-1647).  The median of an even
         count is the upper middle element, like ``sorted(v)[len(v) // 2]``."""
@@ -52,7 +55,9 @@ class Post:
         h, w = img.shape[:2]
         pad = kernelSize // 2
         out = np.zeros((h, w, 3), dtype=img.dtype)
-        if h > 2 * pad and w > 2 * pad:
+        if context is not None:
+            out = context.post_denoise(img, kernelSize)
+        elif h > 2 * pad and w > 2 * pad:
             k = 2 * pad + 1
             win = np.lib.stride_tricks.sliding_window_view(img, (k, k), axis=(0, 1))   # [h-2p, w-2p, 3, k, k]
             flat = np.sort(win.reshape(h - 2 * pad, w - 2 * pad, 3, k * k), axis=-1)
