@@ -12,7 +12,10 @@ one closest-hit query that is traced (primary + bounce + transmit + shadow); sha
 whatever they hit are answered without a ray and not counted (value_in_reference_queries counts them, as the
 reference does).  Consecutive steps are independent frames, and
 several are in flight at a time (--frames-in-flight, config.frames_in_flight), each a chain of its own: a
-context, a stream, a tile buffer; trace, then gather, on that stream.  Prints ONE JSON line on rank 0.
+context, a stream, a tile buffer; trace, then gather, on that stream.  With several ranks one render call carries a
+rank's rows of several consecutive frames (--frames-per-call, config.frames_per_call; t3d_opts.frames), so that a
+rank's launches stay large enough to fill its GPU, and their tiles travel in one gather: every frame is still split
+over all ranks, traced and gathered.  Prints ONE JSON line on rank 0.
 
 The line also carries
   roofline      FP32 vector-ALU roofline of the dominant kernel (k_level, which runs every closest-hit
@@ -99,6 +102,9 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="independent frames traced at the same time, each with a context and a stream of its own "
                          "(0: one for LBVH scenes; brute-force scenes two with one rank, three with two, four with more)")
+    ap.add_argument("--frames-per-call", type=int, default=0,
+                    help="consecutive frames whose rows one render call traces together, and one gather collects "
+                         "(0: as many as there are ranks, so that a call traces a whole frame's worth of rows whatever their number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (RCCL over xGMI, one GPU per rank) or gloo: tiles gathered through host memory, and ranks share the "
@@ -145,6 +151,9 @@ def main():
     # one rank's share of a frame is a chain of small launches: more of them in flight, and full rounds (no slot of a
     # round wasted; the other chains hide the latency the adaptive cut is there to shorten)
     F = args.frames_in_flight if args.frames_in_flight > 0 else (1 if lbvh_scene else (3 if world <= 2 else 4))
+    # One rank's share of a frame shrinks with the number of ranks, and launches that small leave most of a GPU idle:
+    # a call traces the rank's rows of B consecutive frames together (t3d_opts.frames) and one gather moves their tiles.
+    B = args.frames_per_call if args.frames_per_call > 0 else world
     H, W = options["height"], options["width"]
     tile = partition_rows(H, world, rank, args.partition)
     ctxs, outs, streams = [], [], []
@@ -154,24 +163,26 @@ def main():
         c.set_full_rounds(F >= 3)
         c.upload(flat)
         ctxs.append(c)
-        outs.append(torch.empty((tile.nrows, W, 3), dtype=torch.uint8, device=device))
+        outs.append(torch.empty((B, tile.nrows, W, 3) if B > 1 else (tile.nrows, W, 3), dtype=torch.uint8, device=device))
         # explicit streams: a null handle would mean "the context's own stream" to the library, and the gather that
         # follows every render has to be ordered behind it
         streams.append(torch.cuda.Stream(device))
     ctx = ctxs[0]
     counter = [0]
 
-    def step(want_stats):
+    def step(want_stats, frames=B):
+        """One render call on the next chain: this rank's rows of `frames` consecutive frames, then their gather."""
         k = counter[0] % F
         counter[0] += 1
         torch.cuda.set_stream(streams[k])
-        st = ctxs[k].render_rows_device(options, seed, tile.row0, tile.nrows, outs[k].data_ptr(), stream=streams[k].cuda_stream,
-                                        want_stats=want_stats, row_stride=tile.stride)
+        out = outs[k] if frames == B else outs[k][0]
+        st = ctxs[k].render_rows_device(options, seed, tile.row0, tile.nrows, out.data_ptr(), stream=streams[k].cuda_stream,
+                                        want_stats=want_stats, row_stride=tile.stride, frames=frames)
         if gloo:
             streams[k].synchronize()
-            frame = gather_frame(outs[k].cpu(), H, args.partition, slot=k)
+            frame = gather_frame(out.cpu(), H, args.partition, slot=k)
         else:
-            frame = gather_frame(outs[k], H, args.partition, slot=k)
+            frame = gather_frame(out, H, args.partition, slot=k)
         return st, frame
 
     def sync():
@@ -180,22 +191,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    # checked steps, one per chain: counters, and work buffers grown to what this scene's trace trees need
+    # checked calls, one per chain: counters, and work buffers grown to what this scene's trace trees need
     first_stats, frame = step(True)
     for _ in range(F - 1):
         step(True)
     for c in ctxs:
         c.set_timing(False)
-    # untimed steps: the warm-up asked for, and at least as many as every chain needs to reach its steady state (a
-    # band is replayed as a launch graph from its third request with the same counter set, i.e. a chain's fifth step)
-    for _ in range(max(args.warmup - 1, 5 * F)):
+    # the timed region is exactly args.steps frames: calls of B frames, and single frames for what is left over
+    full_calls, single_calls = divmod(args.steps, B) if B > 1 else (args.steps, 0)
+    # untimed calls: the warm-up asked for, and at least as many as every chain needs to reach its steady state (a
+    # band is replayed as a launch graph from its third request with the same counter set, i.e. a chain's fifth call)
+    for _ in range(max((args.warmup + B - 1) // B - 1, 5 * F)):
         step(False)
+    if single_calls:
+        for _ in range(5 * F):
+            step(False, 1)
     sync()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(full_calls):
         step(False)
+    for i in range(single_calls):
+        step(False, 1)
     sync()
     elapsed = time.perf_counter() - t0
+    if single_calls:   # every chain's last call is to be one of B frames for the checks below
+        for _ in range(F):
+            step(False)
+        sync()
     # the timed calls were asynchronous and checked nothing: every chain's last frame must have fitted its buffers
     # and counted the same queries as the checked first step (raises on a capacity overflow)
     for c in ctxs:
@@ -207,14 +229,24 @@ def main():
     # another frame's have no duration of their own
     ctx.set_timing(True)
     torch.cuda.set_stream(streams[0])
-    last = ctx.render_rows_device(options, seed, tile.row0, tile.nrows, outs[0].data_ptr(), stream=streams[0].cuda_stream,
+    alone = torch.empty((tile.nrows, W, 3), dtype=torch.uint8, device=device)
+    last = ctx.render_rows_device(options, seed, tile.row0, tile.nrows, alone.data_ptr(), stream=streams[0].cuda_stream,
                                   want_stats=True, row_stride=tile.stride)
     sync()
-    # every chain rendered the same frame: the tiles left by the timed, replayed, concurrent calls must equal the
-    # tile of the call just made alone
-    for k in range(1, F):
-        if not torch.equal(outs[k], outs[0]):
-            raise RuntimeError(f"the tile of chain {k} differs from the tile rendered alone")
+    # every chain rendered the same frame, B times per call: the tiles left by the timed, replayed, concurrent calls
+    # must equal the tile of the call just made alone
+    for k in range(F):
+        for b, got in enumerate(outs[k] if B > 1 else [outs[k]]):
+            if not torch.equal(got, alone):
+                raise RuntimeError(f"the tile of chain {k}, frame {b} of its call, differs from the tile rendered alone")
+    # counters of the checked call are those of its B frames, which are the same frame
+    for key in list(first_stats):
+        if isinstance(first_stats[key], int) and key not in ("launches", "n_k_level"):
+            if first_stats[key] % B:
+                raise RuntimeError(f"counter {key} of a call of {B} equal frames is not a multiple of {B}")
+            first_stats[key] //= B
+    if first_stats["queries"] != last["queries"]:
+        raise RuntimeError(f"a frame of the checked call traced {first_stats['queries']} queries, the frame rendered alone {last['queries']}")
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
     if world > 1:
@@ -250,7 +282,7 @@ def main():
                        "width": W, "height": H, "bounces": options["bounces"],
                        "samples": options["samples"], "triangles": T, "spheres_and_lights": S,
                        "lights": int(len(flat.light_strength)), "partition": f"{args.partition} rows x{world}",
-                       "frames_in_flight": F,
+                       "frames_in_flight": F * B, "calls_in_flight": F, "frames_per_call": B,
                        "queries_per_frame": traced, "shadow_rays_answered_untraced_per_frame": totals["shadow_culled"],
                        "reference_queries_per_frame": totals["queries"], "rendered_rays_per_frame": totals["rays_api"]},
             "roofline": {"bound": "valu", "kernel": "k_level", "achieved": round(achieved, 3), "peak": FP32_VALU_PEAK_TFLOPS,
@@ -269,7 +301,7 @@ def main():
                          "frac_in_reference_queries": round(last["queries"] * (FLOP_PER_TRI_TEST * T + FLOP_PER_SPHERE_TEST * S)
                                                             / level_s / 1e12 / FP32_VALU_PEAK_TFLOPS, 4) if level_s > 0 else None},
             # the whole pipeline as timed: every flop of the frame over the time a frame takes with F in flight
-            "pipeline": {"frames_in_flight": F, "frame_latency_ms": round(last["ms_device"], 4),
+            "pipeline": {"frames_in_flight": F * B, "frame_latency_ms": round(last["ms_device"], 4),
                          # this rank's share of one frame with nothing else on the device, as a rate
                          "frame_alone_mrays": round(last_traced / (last["ms_device"] * 1e-3) / 1e6, 2) if last["ms_device"] > 0 else None,
                          "achieved": round(flops / (ms_per_step * 1e-3) / 1e12, 3), "unit": "TFLOP/s",

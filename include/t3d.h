@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define T3D_ABI_VERSION 5
+#define T3D_ABI_VERSION 6
 
 enum {
     T3D_OK = 0,
@@ -89,6 +89,13 @@ typedef struct t3d_opts {
     int32_t use_bvh;    /* options['bvh'];  results do not depend on it (conservative culling)     */
     int32_t use_aabb;   /* options['aabb']; likewise                                               */
     int32_t row_stride; /* local row k of a render call is image row row0 + k * row_stride; 0 means 1  */
+    int32_t frames;     /* frames per render call (0 means 1).  A call with frames = B renders the same rows B
+                           times, frame f with the seed `seed + f * frame_seed_step`, and every output array
+                           holds the B results one after the other ([B][nrows][W]...): the pixels are those of B
+                           calls with one frame each, but the launches are B times as large -- for callers whose
+                           share of a frame is too small to fill the device (one rank of several).  No
+                           counterpart in the reference                                                   */
+    uint32_t frame_seed_step;
     double ambient[3];  /* options['ambient'] r,g,b                                                */
 } t3d_opts;
 

@@ -12,7 +12,7 @@ import numpy as np
 from .flatten import FlatScene, Opts, SceneDesc, Stats, make_opts
 
 LIB_PATH = os.environ.get("T3D_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libt3d_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 SYMBOLS = ("t3d_abi_version", "t3d_device_count", "t3d_create", "t3d_destroy", "t3d_last_error",
            "t3d_upload_scene", "t3d_render_rows", "t3d_render_rows_device", "t3d_trace_pixel", "t3d_trace_ray",
@@ -230,21 +230,24 @@ class Context:
         self.flat = flat
 
     def render_rows(self, options: dict, seed: int = 0, row0: int = 0, nrows: int | None = None,
-                    want_radiance=False, want_primary=False, row_stride: int = 1, out=None):
+                    want_radiance=False, want_primary=False, row_stride: int = 1, out=None, frames: int = 1, frame_seed_step: int = 0):
         """-> dict(bgr uint8 [rows,W,3], radiance, prim [rows,W,2], prim_t, stats dict); ``out``: a C-contiguous
-        uint8 array [rows,W,3] (e.g. a block of rows of the caller's image) that receives the pixels in place"""
-        opts = make_opts(options, seed, row_stride=row_stride)
+        uint8 array [rows,W,3] (e.g. a block of rows of the caller's image) that receives the pixels in place.
+        ``frames`` > 1: the rows are rendered that many times in one call, frame f with the seed ``seed + f *
+        frame_seed_step``; every output then has a leading axis of that length"""
+        opts = make_opts(options, seed, row_stride=row_stride, frames=frames, frame_seed_step=frame_seed_step)
         W = opts.width
         nrows = (opts.height - row0 + row_stride - 1) // row_stride if nrows is None else nrows
+        lead = (frames, nrows) if frames > 1 else (nrows,)
         if out is None:
-            bgr = np.empty((nrows, W, 3), np.uint8)
+            bgr = np.empty(lead + (W, 3), np.uint8)
         else:
             bgr = out
-            if bgr.dtype != np.uint8 or bgr.shape != (nrows, W, 3) or not bgr.flags.c_contiguous or not bgr.flags.writeable:
-                raise ValueError(f"out must be a writable C-contiguous uint8 array of shape {(nrows, W, 3)}")
-        rad = np.empty((nrows, W, 3), np.float32) if want_radiance else None
-        prim = np.empty((nrows, W, 2), np.int32) if want_primary else None
-        prim_t = np.empty((nrows, W), np.float32) if want_primary else None
+            if bgr.dtype != np.uint8 or bgr.shape != lead + (W, 3) or not bgr.flags.c_contiguous or not bgr.flags.writeable:
+                raise ValueError(f"out must be a writable C-contiguous uint8 array of shape {lead + (W, 3)}")
+        rad = np.empty(lead + (W, 3), np.float32) if want_radiance else None
+        prim = np.empty(lead + (W, 2), np.int32) if want_primary else None
+        prim_t = np.empty(lead + (W,), np.float32) if want_primary else None
         stats = Stats()
         self._check(self._lib.t3d_render_rows(self._h, C.byref(opts), row0, nrows, _ptr(bgr), _ptr(rad), _ptr(prim),
                                               _ptr(prim_t), C.byref(stats)), "t3d_render_rows")
@@ -260,10 +263,11 @@ class Context:
 
     def render_rows_device(self, options: dict, seed: int, row0: int, nrows: int, bgr_ptr: int, radiance_ptr: int = 0,
                            primary_ptr: int = 0, primary_t_ptr: int = 0, stream: int = 0, want_stats=True,
-                           row_stride: int = 1, static=False):
+                           row_stride: int = 1, static=False, frames: int = 1, frame_seed_step: int = 0):
         """Outputs go to caller-owned device memory (raw addresses, e.g. ``tensor.data_ptr()``).  ``static``: through
-        ``t3d_render_rows_device_static``, which allocates nothing (work buffers in the library's per-GPU static array)."""
-        opts = make_opts(options, seed, row_stride=row_stride)
+        ``t3d_render_rows_device_static``, which allocates nothing (work buffers in the library's per-GPU static array).
+        ``frames`` > 1: the outputs hold that many frames of ``nrows`` rows, one after the other (``make_opts``)."""
+        opts = make_opts(options, seed, row_stride=row_stride, frames=frames, frame_seed_step=frame_seed_step)
         stats = Stats() if want_stats else None
         fn = self._lib.t3d_render_rows_device_static if static else self._lib.t3d_render_rows_device
         self._check(fn(

@@ -136,6 +136,8 @@ struct DevScene {
 
 struct RenderParams {
     int width, height, row0, nrows, row_stride;
+    int vrow0, frame_rows;   // several frames per call: local row k of the band is row (vrow0 + k) % frame_rows of frame (vrow0 + k) / frame_rows; frame_rows 0: one frame, row vrow0 + k
+    uint32_t seed_step;      // seed of frame f: seed + f * seed_step
     int bounces, samples, lights;
     uint32_t seed;
     float ambient[3];
@@ -1070,9 +1072,12 @@ __device__ __forceinline__ void load_ray(const DevScene& sc, const RenderParams&
             in.smp = in.i - pix * rp.samples;
             int ly = pix / rp.width;
             in.px = pix - ly * rp.width;
-            in.py = rp.row0 + ly * rp.row_stride;
+            int vrow = rp.vrow0 + ly;
+            uint32_t seed = rp.seed;
+            if (rp.frame_rows) { const int frame = vrow / rp.frame_rows; vrow -= frame * rp.frame_rows; seed += (uint32_t)frame * rp.seed_step; }
+            in.py = rp.row0 + vrow * rp.row_stride;
             if (single) { in.px = rp.px0; in.py = rp.py0; in.smp = rp.sample0; }
-            in.pixel_hash = keyed_pixel_hash(rp.seed, (uint32_t)in.px, (uint32_t)in.py);
+            in.pixel_hash = keyed_pixel_hash(seed, (uint32_t)in.px, (uint32_t)in.py);
             in.heap = (((uint32_t)in.smp & 0xFFFFu) << 16) | 1u;
             if (single == 2) {
                 in.o = mk(rp.ray_o[0], rp.ray_o[1], rp.ray_o[2]); in.d = mk(rp.ray_d[0], rp.ray_d[1], rp.ray_d[2]);
@@ -2092,6 +2097,7 @@ static int check_opts(t3d_ctx* c, const t3d_opts* o, int row0, int nrows) {
     if (o->samples > 65535) { c->err = "samples above the supported maximum (65535)"; return T3D_E_CAPACITY; }
     if (!std::isfinite(o->ambient[0]) || !std::isfinite(o->ambient[1]) || !std::isfinite(o->ambient[2])) { c->err = "ambient colour is not finite"; return T3D_E_INVALID; }
     if (o->rng_mode != T3D_RNG_KEYED) { c->err = "the HIP library implements the keyed random mode only"; return T3D_E_INVALID; }
+    if (o->frames < 0 || (o->frames > 1 && (long)o->frames * nrows > 0x3FFFFFFF)) { c->err = "bad number of frames per call"; return T3D_E_INVALID; }
     {
         long stride = o->row_stride > 1 ? o->row_stride : 1;
         if (row0 < 0 || nrows <= 0 || row0 + (long)(nrows - 1) * stride >= o->height) { c->err = "row range outside the image"; return T3D_E_INVALID; }
@@ -2164,7 +2170,7 @@ static void fill_stats(t3d_ctx* c, t3d_stats* stats) {
 // Trace one band whose outputs are device pointers, with the work buffers `w` (grown as needed unless `fixed_work`:
 // then `w` has been laid out by the caller and must already hold `cap_factor` entries per primary sample).  Returns
 // T3D_E_CAPACITY if a level overflowed its queue (the caller retries with a larger capacity factor or fewer rows).
-static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int nrows, int cap_factor, uint8_t* d_bgr, float* d_rad,
+static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int frame_rows, int vrow0, int nrows, int cap_factor, uint8_t* d_bgr, float* d_rad,
                        int32_t* d_prim, float* d_prim_t, hipStream_t st, t3d_stats* stats, const RenderParams* single,
                        t3d_node* d_dbg, int dbg_cap, bool fixed_work = false, size_t min_cap = 0) {
     const int S = o->bounces > 1 ? o->samples : 1;  // T3DR.py:1209
@@ -2188,6 +2194,7 @@ static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int nro
     RenderParams rp{};
     rp.width = o->width; rp.height = o->height; rp.row0 = row0; rp.nrows = single ? 1 : nrows;
     rp.row_stride = o->row_stride > 1 ? o->row_stride : 1;
+    rp.vrow0 = single ? 0 : vrow0; rp.frame_rows = !single && o->frames > 1 ? frame_rows : 0; rp.seed_step = o->frame_seed_step;
     rp.bounces = o->bounces; rp.samples = single ? 1 : S; rp.lights = o->lights; rp.seed = o->seed;
     for (int k = 0; k < 3; ++k) rp.ambient[k] = (float)o->ambient[k];
     rp.cap = (int)(fixed_work ? cap : w.cap);
@@ -2442,13 +2449,15 @@ extern "C" int t3d_render_rows_device(t3d_ctx* c, const t3d_opts* o, int row0, i
     if (max_samples > max_idx) max_samples = max_idx;
     int band = (int)(max_samples / ((size_t)o->width * S));
     if (band < 1) band = 1;
-    if (band > nrows) band = nrows;
+    // the rows of the call, all its frames one after the other (bands may straddle frames)
+    const int vrows = nrows * (o->frames > 1 ? o->frames : 1);
+    if (band > vrows) band = vrows;
     // a level holds at most 2^bounces rays per sample; a band of few samples is worked on by few waves, whose
     // rays all land in those waves' shards, so the bound on the factor counts every shard
     const int factor_limit = (1 << o->bounces) * T3D_SHARDS;
-    for (int r = 0; r < nrows;) {
+    for (int r = 0; r < vrows;) {
         if (c->cancel_cb && c->cancel_cb(c->cancel_user)) { c->last_valid = false; c->err = "render cancelled by the caller's cancel callback"; return T3D_E_CANCELLED; }
-        int nb = band < nrows - r ? band : nrows - r;
+        int nb = band < vrows - r ? band : vrows - r;
         size_t off = (size_t)r * o->width;
         // a call without stats cannot see an overflow and try again: it starts from what earlier overflows have taught
         int factor = 2;
@@ -2456,7 +2465,7 @@ extern "C" int t3d_render_rows_device(t3d_ctx* c, const t3d_opts* o, int row0, i
         for (;;) {
             t3d_stats band_stats{};
             // capacity overflow can only be seen after a synchronisation; without stats the call stays asynchronous
-            rc = render_band(c, c->work, o, row0 + r * (o->row_stride > 1 ? o->row_stride : 1), nb, factor, bgr_device + 3 * off, radiance_device ? radiance_device + 3 * off : nullptr,
+            rc = render_band(c, c->work, o, row0, nrows, r, nb, factor, bgr_device + 3 * off, radiance_device ? radiance_device + 3 * off : nullptr,
                              primary_device ? primary_device + 2 * off : nullptr, primary_t_device ? primary_t_device + off : nullptr, st,
                              stats ? &band_stats : nullptr, nullptr, nullptr, 0, false, min_cap);
             if (rc == T3D_E_CAPACITY && factor < factor_limit) {
@@ -2542,17 +2551,18 @@ extern "C" int t3d_render_rows_device_static(t3d_ctx* c, const t3d_opts* o, int 
         c->err = "t3d_render_rows_device_static: one image row of this width, depth and light count does not fit the static work array (128 MiB)";
         return T3D_E_CAPACITY;
     }
+    const int vrows = nrows * (o->frames > 1 ? o->frames : 1);   // the rows of the call, all its frames one after the other
     int band = 1;   // the largest number of rows whose optimistic working set (two rays per sample and level) fits
-    for (int lo = 1, hi = nrows; lo <= hi;) { const int mid = lo + (hi - lo) / 2; if (fits(mid, factor0)) { band = mid; lo = mid + 1; } else hi = mid - 1; }
-    for (int r = 0; r < nrows;) {
+    for (int lo = 1, hi = vrows; lo <= hi;) { const int mid = lo + (hi - lo) / 2; if (fits(mid, factor0)) { band = mid; lo = mid + 1; } else hi = mid - 1; }
+    for (int r = 0; r < vrows;) {
         if (c->cancel_cb && c->cancel_cb(c->cancel_user)) { c->last_valid = false; c->err = "render cancelled by the caller's cancel callback"; return T3D_E_CANCELLED; }
-        int nb = band < nrows - r ? band : nrows - r;
+        int nb = band < vrows - r ? band : vrows - r;
         int factor = factor0;
         const size_t off = (size_t)r * o->width;
         for (;;) {
             if (!fits(nb, factor)) { c->err = "t3d_render_rows_device_static: trace tree does not fit the static work array (128 MiB)"; return T3D_E_CAPACITY; }
             t3d_stats band_stats{};
-            rc = render_band(c, w, o, row0 + r * (o->row_stride > 1 ? o->row_stride : 1), nb, factor, bgr_device + 3 * off,
+            rc = render_band(c, w, o, row0, nrows, r, nb, factor, bgr_device + 3 * off,
                              radiance_device ? radiance_device + 3 * off : nullptr, primary_device ? primary_device + 2 * off : nullptr,
                              primary_t_device ? primary_t_device + off : nullptr, st, stats ? &band_stats : nullptr, nullptr, nullptr, 0, true);
             if (rc == T3D_E_CAPACITY) {
@@ -2723,7 +2733,7 @@ extern "C" int t3d_render_rows(t3d_ctx* c, const t3d_opts* o, int row0, int nrow
     if (rc) return rc;
     if (!bgr_out) { c->err = "bgr output is required"; return T3D_E_INVALID; }
     HIPCHK(c, hipSetDevice(c->device));
-    size_t npix = (size_t)nrows * o->width;
+    size_t npix = (size_t)nrows * (o->frames > 1 ? o->frames : 1) * o->width;
     if ((rc = ensure_outputs(c, npix)) != T3D_OK) return rc;
     t3d_stats local{};
     rc = t3d_render_rows_device(c, o, row0, nrows, c->d_bgr, radiance_out ? c->d_rad : nullptr, primary_out ? c->d_prim : nullptr,
@@ -2771,7 +2781,7 @@ extern "C" int t3d_render_rows_async(t3d_ctx* c, const t3d_opts* o, int row0, in
     if (rc) return rc;
     if (!bgr_pinned) { c->err = "bgr output is required"; return T3D_E_INVALID; }
     HIPCHK(c, hipSetDevice(c->device));
-    const size_t npix = (size_t)nrows * o->width;
+    const size_t npix = (size_t)nrows * (o->frames > 1 ? o->frames : 1) * o->width;
     if ((rc = ensure_outputs(c, npix)) != T3D_OK) return rc;
     rc = t3d_render_rows_device(c, o, row0, nrows, c->d_bgr, nullptr, nullptr, nullptr, nullptr, nullptr);
     if (rc) return rc;
@@ -2798,7 +2808,7 @@ extern "C" int t3d_render_frame_multi(t3d_ctx* const* ctxs, int n, const t3d_opt
     auto work = [&](int k) {
         t3d_ctx* c = ctxs[k];
         t3d_opts ok = *o;
-        ok.row_stride = n;
+        ok.row_stride = n; ok.frames = 1;
         int rc = check_opts(c, &ok, k, rows);
         if (rc == T3D_OK && hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; rc = T3D_E_DEVICE; }
         if (rc == T3D_OK) rc = ensure_outputs(c, (size_t)rows * o->width);
@@ -2863,7 +2873,7 @@ static int trace_single(t3d_ctx* c, const t3d_opts* o, const RenderParams& singl
     // The whole tree lives in one queue shard (render_band uses a single shard and a single workgroup for it), and a
     // level of it holds at most 2^bounces rays: that is all the capacity a level needs.
     const int factor = 1 << o->bounces;
-    rc = render_band(c, c->single_work, o, row, 1, factor, nullptr, nullptr, nullptr, nullptr, c->stream, &st, &single, d_dbg, dbg_cap);
+    rc = render_band(c, c->single_work, o, row, 1, 0, 1, factor, nullptr, nullptr, nullptr, nullptr, c->stream, &st, &single, d_dbg, dbg_cap);
     int n = 0;
     if (!rc) {
         n = c->h_cnt->n_dbg < dbg_cap ? c->h_cnt->n_dbg : dbg_cap;

@@ -46,7 +46,8 @@ class Opts(C.Structure):
     """ctypes mirror of ``t3d_opts``."""
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("bounces", C.c_int32), ("samples", C.c_int32),
                 ("lights", C.c_int32), ("rng_mode", C.c_int32), ("seed", C.c_uint32), ("use_bvh", C.c_int32),
-                ("use_aabb", C.c_int32), ("row_stride", C.c_int32), ("ambient", C.c_double * 3)]
+                ("use_aabb", C.c_int32), ("row_stride", C.c_int32), ("frames", C.c_int32), ("frame_seed_step", C.c_uint32),
+                ("ambient", C.c_double * 3)]
 
 
 class Stats(C.Structure):
@@ -65,8 +66,10 @@ class Stats(C.Structure):
 RNG_KEYED, RNG_MT_SERIAL = 0, 1
 
 
-def make_opts(options: dict, seed: int = 0, rng_mode: int = RNG_KEYED, row_stride: int = 1) -> Opts:
-    """Photon options dict (T3DR.py:519-525) -> ``t3d_opts``."""
+def make_opts(options: dict, seed: int = 0, rng_mode: int = RNG_KEYED, row_stride: int = 1, frames: int = 1,
+              frame_seed_step: int = 0) -> Opts:
+    """Photon options dict (T3DR.py:519-525) -> ``t3d_opts``.  ``frames`` > 1: the call renders its rows that many
+    times, frame f with the seed ``seed + f * frame_seed_step``, into outputs that hold the frames one after the other."""
     amb = options.get("ambient", (20, 20, 20))
     o = Opts()
     o.width, o.height = int(options["width"]), int(options["height"])
@@ -76,6 +79,7 @@ def make_opts(options: dict, seed: int = 0, rng_mode: int = RNG_KEYED, row_strid
     o.use_bvh = 1 if options.get("bvh", True) else 0
     o.use_aabb = 1 if options.get("aabb", True) else 0
     o.row_stride = int(row_stride)
+    o.frames, o.frame_seed_step = int(frames), int(frame_seed_step) & 0xFFFFFFFF
     o.ambient[:] = [float(c) for c in amb]
     return o
 

@@ -64,17 +64,25 @@ _workspace = {}   # receive buffer and frame per gather shape and stream (rank d
 def gather_frame(tile, height: int, mode: str = "interleaved", group=None, dst: int = 0, slot: int = 0):
     """Collect every rank's tile on rank ``dst`` and return the assembled frame there (``None`` on
     the other ranks).  ``tile`` is a torch tensor [H/G, W, C] on the device the backend moves
-    (GPU for nccl/RCCL, CPU for gloo).  Single-process use returns the tile's own frame.  The returned
-    frame is a buffer that the next call with the same shapes, stream and ``slot`` overwrites: a caller that
-    keeps several frames in flight gives each chain a slot (and, on a GPU, a stream) of its own."""
+    (GPU for nccl/RCCL, CPU for gloo) -- or [B, H/G, W, C], the tiles of B frames rendered by one call: they
+    travel in one collective and come back as frames [B, H, W, C].  Single-process use returns the tile's own
+    frame.  The returned frame is a buffer that the next call with the same shapes, stream and ``slot``
+    overwrites: a caller that keeps several frames in flight gives each chain a slot (and, on a GPU, a stream)
+    of its own."""
     import torch.distributed as dist
 
+    batched = tile.ndim == 4
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return tile if tile.shape[0] == height else assemble([tile], height, mode)   # one rank: the tile is the frame
+        if tile.shape[-3] == height:
+            return tile                                                      # one rank: the tile is the frame
+        if batched:
+            import torch
+            return torch.stack([assemble([t], height, mode) for t in tile])
+        return assemble([tile], height, mode)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     tile = tile.contiguous()
     if rank == dst:
-        # one receive buffer [G, H/G, W, C] and one frame, kept between calls; the tiles land in the buffer
+        # one receive buffer [G, (B,) H/G, W, C] and one frame, kept between calls; the tiles land in the buffer
         # and a single strided copy puts the rows in place
         # per stream: two frames in flight on two streams must not share a receive buffer
         stream_id = 0
@@ -87,12 +95,15 @@ def gather_frame(tile, height: int, mode: str = "interleaved", group=None, dst: 
             if len(_workspace) > 16:
                 _workspace.clear()
             stacked = tile.new_empty((world,) + tuple(tile.shape))
-            frame = tile.new_empty((height,) + tuple(tile.shape[1:]))
+            lead, rest = tuple(tile.shape[:-3]), tuple(tile.shape[-2:])     # (B,) or (), and (W, C)
+            frame = tile.new_empty(lead + (height,) + rest)
             n = height // world
+            b = len(lead)                                                    # 0 or 1: where the row axes start in `frame`
+            ranks_last = list(range(1, 1 + b)) + [0] + list(range(1 + b, stacked.ndim))   # [G, (B,) n, ...] -> [(B,) G, n, ...]
             if mode == "bands":
-                dst_view, src_view = frame.view((world, n) + tuple(tile.shape[1:])), stacked
+                dst_view, src_view = frame.view(lead + (world, n) + rest), stacked.permute(ranks_last)
             elif mode == "interleaved":
-                dst_view, src_view = frame.view((n, world) + tuple(tile.shape[1:])), stacked.transpose(0, 1)
+                dst_view, src_view = frame.view(lead + (n, world) + rest), stacked.permute(ranks_last).transpose(b, b + 1)
             else:
                 raise ValueError(f"unknown partition mode {mode!r}")
             # the per-rank views and the two sides of the copy are made once: this runs every frame

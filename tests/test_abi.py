@@ -36,13 +36,15 @@ def test_ctypes_layout_matches_c(tmp_path):
     src = tmp_path / "layout.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "t3d.h"\nint main(void){'
                    'printf("%zu %zu %zu %zu ", sizeof(t3d_scene_desc), sizeof(t3d_opts), sizeof(t3d_stats), sizeof(t3d_node));'
-                   'printf("%zu %zu %zu %zu %zu\\n", offsetof(t3d_scene_desc, cam_pos), offsetof(t3d_opts, ambient),'
-                   'offsetof(t3d_opts, row_stride), offsetof(t3d_stats, ms_device), offsetof(t3d_node, color));return 0;}')
+                   'printf("%zu %zu %zu %zu %zu ", offsetof(t3d_scene_desc, cam_pos), offsetof(t3d_opts, ambient),'
+                   'offsetof(t3d_opts, row_stride), offsetof(t3d_stats, ms_device), offsetof(t3d_node, color));'
+                   'printf("%zu %zu\\n", offsetof(t3d_opts, frames), offsetof(t3d_opts, frame_seed_step));return 0;}')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [C.sizeof(SceneDesc), C.sizeof(Opts), C.sizeof(Stats), C.sizeof(_native.Node), SceneDesc.cam_pos.offset,
-            Opts.ambient.offset, Opts.row_stride.offset, Stats.ms_device.offset, _native.Node.color.offset]
+            Opts.ambient.offset, Opts.row_stride.offset, Stats.ms_device.offset, _native.Node.color.offset,
+            Opts.frames.offset, Opts.frame_seed_step.offset]
     assert got == want
 
 

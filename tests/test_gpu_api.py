@@ -147,6 +147,67 @@ def test_frame_on_several_contexts(accel):
             c.close()
 
 
+@pytest.mark.parametrize("accel", ["brute", "lbvh"])
+def test_several_frames_per_call(accel, monkeypatch):
+    """t3d_opts.frames: one call renders its rows several times, frame f with the seed seed + f * frame_seed_step, into
+    outputs that hold the frames one after the other -- pixel for pixel (image, radiance, primary hits) what separate calls
+    give, and the counters are their sums; also when the call is cut into bands that straddle frames, with a row stride,
+    through device pointers, and with the entry point that allocates nothing."""
+    import torch
+    from raytracing_amd import _native
+    flat = flat_for("config2_cornell_light.json")
+    opt = dict(width=48, height=45, bounces=3, samples=2)
+
+    def context():
+        c = _native.Context(0)
+        c.set_accel(accel)
+        c.upload(flat)
+        return c
+
+    ctx = context()
+    try:
+        B, step, seed = 3, 5, 11
+        single = [ctx.render_rows(opt, seed=seed + f * step, row0=2, nrows=9, row_stride=5, want_radiance=True, want_primary=True) for f in range(B)]
+        assert not np.array_equal(single[0]["bgr"], single[1]["bgr"])      # the seeds matter in this scene
+        got = ctx.render_rows(opt, seed=seed, row0=2, nrows=9, row_stride=5, want_radiance=True, want_primary=True, frames=B, frame_seed_step=step)
+        assert got["bgr"].shape == (B, 9, 48, 3)
+        for f in range(B):
+            for k in ("bgr", "radiance", "prim"):
+                assert np.array_equal(got[k][f], single[f][k]), (k, f)
+            assert np.array_equal(got["prim_t"][f], single[f]["prim_t"], equal_nan=True)
+        for k in ("queries", "rays_api", "nodes", "shadow_queries", "trace_queries", "shadow_culled"):
+            assert got["stats"][k] == sum(s["stats"][k] for s in single), k
+        # a step of zero: B copies of the same frame
+        same = ctx.render_rows(opt, seed=seed, row0=2, nrows=9, row_stride=5, frames=2)
+        assert np.array_equal(same["bgr"][0], single[0]["bgr"]) and np.array_equal(same["bgr"][1], single[0]["bgr"])
+        # device pointers, asynchronous, and the entry point that allocates nothing
+        for static in (False, True):
+            out = torch.zeros((B, 9, 48, 3), dtype=torch.uint8, device="cuda:0")
+            stream = torch.cuda.Stream()
+            for attempt in range(3):       # an asynchronous call may first have to learn the capacity the trees need
+                ctx.render_rows_device(opt, seed, 2, 9, out.data_ptr(), stream=stream.cuda_stream, want_stats=False, row_stride=5,
+                                       static=static, frames=B, frame_seed_step=step)
+                try:
+                    ctx.last_call_stats()
+                    break
+                except _native.NativeError as e:
+                    assert e.code == _native.E_CAPACITY
+            assert np.array_equal(out.cpu().numpy(), got["bgr"]), static
+        with pytest.raises(_native.NativeError):
+            ctx.render_rows(opt, seed=seed, row0=2, nrows=9, row_stride=5, frames=-1)
+    finally:
+        ctx.close()
+    # bands of a few rows each, which straddle the frames
+    monkeypatch.setenv("T3D_MEM_BUDGET_MB", "1")
+    ctx = context()
+    try:
+        banded = ctx.render_rows(opt, seed=seed, row0=2, nrows=9, row_stride=5, want_radiance=True, frames=B, frame_seed_step=step)
+        assert banded["stats"]["n_k_level"] >= 4 * 2, "the call was meant to be cut into several bands"
+        assert np.array_equal(banded["bgr"], got["bgr"]) and np.array_equal(banded["radiance"], got["radiance"])
+    finally:
+        ctx.close()
+
+
 def test_frame_on_several_contexts_into_device_memory():
     import torch
     from raytracing_amd import _native
@@ -274,6 +335,8 @@ def test_bench_with_two_ranks_rehearsed_on_one_gpu():
     assert d["config"]["reference_queries_per_frame"] == 17874992          # both halves of the frame, summed over the ranks
     assert d["config"]["queries_per_frame"] + d["config"]["shadow_rays_answered_untraced_per_frame"] == 17874992
     assert d["value"] > 0 and "cpu_baseline" not in d          # the CPU baseline is a one-rank field
+    # a call carries a rank's rows of two frames; the three timed frames are one such call and one single frame
+    assert d["config"]["frames_per_call"] == 2 and d["config"]["frames_in_flight"] == 2 * d["config"]["calls_in_flight"]
 
 
 def test_bench_with_two_ranks_over_rccl():

@@ -109,3 +109,37 @@ def test_gathers_of_several_frames_in_flight_gloo():
         ret = mgr.dict()
         mp.spawn(_worker_in_flight, args=(world, _free_port(), ret), nprocs=world, join=True)
         assert ret.get("ok") is True
+
+
+def _worker_batched(rank, world, port, mode, ret):
+    """Tiles of three frames from one render call travel in one gather: [B, H/G, W, C] -> frames [B, H, W, C]."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        H, W, B = 12, 4, 3
+        t = partition_rows(H, world, rank, mode)
+        rows = torch.tensor(list(t.rows()), dtype=torch.uint8)
+        # pixel value = image row + 50 * frame
+        tile = torch.stack([(rows + 50 * f).view(-1, 1, 1).expand(t.nrows, W, 3) for f in range(B)]).contiguous()
+        frames = gather_frame(tile, H, mode)
+        if rank == 0:
+            want = torch.arange(H, dtype=torch.uint8).view(1, H) + 50 * torch.arange(B, dtype=torch.uint8).view(B, 1)
+            ret["ok"] = tuple(frames.shape) == (B, H, W, 3) and bool((frames[:, :, 1, 2] == want).all()) and bool((frames[:, :, 3, 0] == want).all())
+        else:
+            assert frames is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["interleaved", "bands"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_of_a_batch_of_frames_gloo(mode, world):
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_batched, args=(world, _free_port(), mode, ret), nprocs=world, join=True)
+        assert ret.get("ok") is True
+
+
+def test_single_process_batch_is_its_own_frames():
+    tile = torch.arange(2 * 6 * 4 * 3, dtype=torch.uint8).view(2, 6, 4, 3)
+    assert gather_frame(tile, 6) is tile
