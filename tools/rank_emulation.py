@@ -76,7 +76,7 @@ for n in ([int(a) for a in args] or [1, 2, 4, 8]):
     torch.cuda.set_stream(torch_stream)
     ms = (time.perf_counter() - t0) / (K * B) * 1e3
     ctx.set_timing(True)
-    print(f"ranks {n}: rows {rows}  {ms:.4f} ms/frame per rank  queries {st['queries']}  -> speedup bound {0:.2f}" if n == 1 else
-          f"ranks {n}: rows {rows}  {ms:.4f} ms/frame per rank ({F} calls in flight, {B} frames per call{', gather' if with_gather else ''}; host {host_ms:.4f} ms/frame)  queries {st['queries']}")
+    print(f"ranks {n} ({workload}): rows {rows}  {ms:.4f} ms/frame per rank ({F} calls in flight, {B} frames per call)  queries {st['queries']}  -> speedup bound {0:.2f}" if n == 1 else
+          f"ranks {n} ({workload}): rows {rows}  {ms:.4f} ms/frame per rank ({F} calls in flight, {B} frames per call{', gather' if with_gather else ''}; host {host_ms:.4f} ms/frame)  queries {st['queries']}")
     print("   k_level ms per level", [round(x, 4) for x in st["level_ms"][:opt["bounces"] + 1]], "resolve+finish ms", round(st["ms_resolve"], 4),
           "rays per level", st["level_rays"][:opt["bounces"] + 1], "nodes", st["level_nodes"][:opt["bounces"] + 1])
