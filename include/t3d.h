@@ -93,8 +93,10 @@ typedef struct t3d_opts {
                            times, frame f with the seed `seed + f * frame_seed_step`, and every output array
                            holds the B results one after the other ([B][nrows][W]...): the pixels are those of B
                            calls with one frame each, but the launches are B times as large -- for callers whose
-                           share of a frame is too small to fill the device (one rank of several).  No
-                           counterpart in the reference                                                   */
+                           share of a frame is too small to fill the device (one rank of several).  Honoured by
+                           t3d_render_rows, _device, _device_static and _async; t3d_render_frame_multi and the
+                           single-ray entry points render one frame whatever it says.  No counterpart in the
+                           reference                                                                      */
     uint32_t frame_seed_step;
     double ambient[3];  /* options['ambient'] r,g,b                                                */
 } t3d_opts;
