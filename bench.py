@@ -175,7 +175,7 @@ def main():
         k = counter[0] % F
         counter[0] += 1
         torch.cuda.set_stream(streams[k])
-        out = outs[k] if frames == B else outs[k][0]
+        out = outs[k] if frames == B else outs[k][:frames]
         st = ctxs[k].render_rows_device(options, seed, tile.row0, tile.nrows, out.data_ptr(), stream=streams[k].cuda_stream,
                                         want_stats=want_stats, row_stride=tile.stride, frames=frames)
         if gloo:
@@ -197,24 +197,24 @@ def main():
         step(True)
     for c in ctxs:
         c.set_timing(False)
-    # the timed region is exactly args.steps frames: calls of B frames, and single frames for what is left over
-    full_calls, single_calls = divmod(args.steps, B) if B > 1 else (args.steps, 0)
+    # the timed region is exactly args.steps frames: calls of B frames, and one smaller call for what is left over
+    full_calls, rest = divmod(args.steps, B) if B > 1 else (args.steps, 0)
     # untimed calls: the warm-up asked for, and at least as many as every chain needs to reach its steady state (a
     # band is replayed as a launch graph from its third request with the same counter set, i.e. a chain's fifth call)
     for _ in range(max((args.warmup + B - 1) // B - 1, 5 * F)):
         step(False)
-    if single_calls:
+    if rest:
         for _ in range(5 * F):
-            step(False, 1)
+            step(False, rest)
     sync()
     t0 = time.perf_counter()
     for i in range(full_calls):
         step(False)
-    for i in range(single_calls):
-        step(False, 1)
+    if rest:
+        step(False, rest)
     sync()
     elapsed = time.perf_counter() - t0
-    if single_calls:   # every chain's last call is to be one of B frames for the checks below
+    if rest:   # every chain's last call is to be one of B frames for the checks below
         for _ in range(F):
             step(False)
         sync()

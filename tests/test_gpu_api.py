@@ -335,7 +335,7 @@ def test_bench_with_two_ranks_rehearsed_on_one_gpu():
     assert d["config"]["reference_queries_per_frame"] == 17874992          # both halves of the frame, summed over the ranks
     assert d["config"]["queries_per_frame"] + d["config"]["shadow_rays_answered_untraced_per_frame"] == 17874992
     assert d["value"] > 0 and "cpu_baseline" not in d          # the CPU baseline is a one-rank field
-    # a call carries a rank's rows of two frames; the three timed frames are one such call and one single frame
+    # a call carries a rank's rows of two frames; the three timed frames are one such call and one call of a single frame
     assert d["config"]["frames_per_call"] == 2 and d["config"]["frames_in_flight"] == 2 * d["config"]["calls_in_flight"]
 
 
