@@ -2641,7 +2641,7 @@ extern "C" int t3d_set_cancel(t3d_ctx* c, int (*poll)(void*), void* user) {
 extern "C" int t3d_post_upscale_device(t3d_ctx* c, const uint8_t* in_device, int height, int width, int channels, int factor,
                                        uint8_t* out_device, void* stream) {
     if (!c) return T3D_E_INVALID;
-    if (!in_device || !out_device || height <= 0 || width <= 0 || channels <= 0 || channels > 16 || factor <= 0) { c->err = "t3d_post_upscale: bad argument"; return T3D_E_INVALID; }
+    if (!in_device || !out_device || height <= 0 || width <= 0 || channels <= 0 || factor <= 0) { c->err = "t3d_post_upscale: bad argument"; return T3D_E_INVALID; }
     if (height > 65535 || (long long)width * factor * channels > (1ll << 31)) { c->err = "t3d_post_upscale: output too large"; return T3D_E_CAPACITY; }
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;

@@ -21,7 +21,7 @@ def _host_denoise(img, k):
 
 @pytest.mark.parametrize("shape,factor", [((5, 7, 3), 1), ((5, 7, 3), 2), ((33, 65, 3), 3), ((9, 4, 1), 4), ((17, 300, 4), 5),
                                           ((1, 1, 3), 7), ((270, 480, 3), 4), ((6, 6, 3), 2), ((3, 5, 2), 3),
-                                          ((2, 1000, 3), 16)])
+                                          ((2, 1000, 3), 16), ((3, 4, 20), 2)])
 def test_upscale_matches_host(ctx, shape, factor):
     rng = np.random.default_rng(shape[0] * 131 + factor)
     img = rng.integers(0, 256, size=shape, dtype=np.uint8)
