@@ -177,6 +177,11 @@ def test_several_frames_per_call(accel, monkeypatch):
             assert np.array_equal(got["prim_t"][f], single[f]["prim_t"], equal_nan=True)
         for k in ("queries", "rays_api", "nodes", "shadow_queries", "trace_queries", "shadow_culled"):
             assert got["stats"][k] == sum(s["stats"][k] for s in single), k
+        # 2 x 12 rows: a band whose rays are walked in 16 x 8 pixel tiles, one of which straddles the two frames
+        two = ctx.render_rows(opt, seed=seed, row0=1, nrows=12, row_stride=3, want_radiance=True, frames=2, frame_seed_step=step)
+        for f in range(2):
+            one = ctx.render_rows(opt, seed=seed + f * step, row0=1, nrows=12, row_stride=3, want_radiance=True)
+            assert np.array_equal(two["bgr"][f], one["bgr"]) and np.array_equal(two["radiance"][f], one["radiance"]), f
         # a step of zero: B copies of the same frame
         same = ctx.render_rows(opt, seed=seed, row0=2, nrows=9, row_stride=5, frames=2)
         assert np.array_equal(same["bgr"][0], single[0]["bgr"]) and np.array_equal(same["bgr"][1], single[0]["bgr"])
