@@ -344,6 +344,16 @@ def test_bench_with_two_ranks_rehearsed_on_one_gpu():
     assert d["config"]["frames_per_call"] == 2 and d["config"]["frames_in_flight"] == 2 * d["config"]["calls_in_flight"]
 
 
+def test_bench_with_four_ranks_rehearsed_on_one_gpu():
+    """Four ranks: a call carries a rank's 270 rows of four frames, whose pixel tiles (eight rows high) straddle the frames;
+    bench.py itself compares every frame of every chain's last call with the tile rendered alone and raises on a difference."""
+    d = _run_bench_ranks(4, ["--dist-backend", "gloo"])
+    assert d["n_gpus"] == 4 and d["config"]["partition"] == "interleaved rows x4" and d["steps"] == 3
+    assert d["config"]["frames_per_call"] == 4 and d["config"]["calls_in_flight"] == 4 and d["config"]["frames_in_flight"] == 16
+    assert d["config"]["reference_queries_per_frame"] == 17874992
+    assert d["config"]["queries_per_frame"] + d["config"]["shadow_rays_answered_untraced_per_frame"] == 17874992
+
+
 def test_bench_with_two_ranks_over_rccl():
     """The same with the RCCL backend, one GPU per rank: runs where two GPUs are visible."""
     from raytracing_amd import _native
