@@ -61,6 +61,24 @@ def assemble(tiles, height: int, mode: str = "interleaved"):
 _workspace = {}   # receive buffer and frame per gather shape and stream (rank dst only)
 
 
+def _gather_workspace(tile, world: int, height: int, mode: str):
+    """Receive buffer [G, (B,) H/G, W, C] with its per-rank views, the frame(s) [(B,) H, W, C], and the two sides of
+    the one strided copy that puts the received rows in place: made once per shape, used every frame."""
+    stacked = tile.new_empty((world,) + tuple(tile.shape))
+    lead, rest = tuple(tile.shape[:-3]), tuple(tile.shape[-2:])     # (B,) or (), and (W, C)
+    frame = tile.new_empty(lead + (height,) + rest)
+    n = height // world
+    b = len(lead)                                                    # 0 or 1: where the row axes start in `frame`
+    ranks_last = list(range(1, 1 + b)) + [0] + list(range(1 + b, stacked.ndim))   # [G, (B,) n, ...] -> [(B,) G, n, ...]
+    if mode == "bands":
+        dst_view, src_view = frame.view(lead + (world, n) + rest), stacked.permute(ranks_last)
+    elif mode == "interleaved":
+        dst_view, src_view = frame.view(lead + (n, world) + rest), stacked.permute(ranks_last).transpose(b, b + 1)
+    else:
+        raise ValueError(f"unknown partition mode {mode!r}")
+    return [stacked[r] for r in range(world)], frame, dst_view, src_view
+
+
 def gather_frame(tile, height: int, mode: str = "interleaved", group=None, dst: int = 0, slot: int = 0):
     """Collect every rank's tile on rank ``dst`` and return the assembled frame there (``None`` on
     the other ranks).  ``tile`` is a torch tensor [H/G, W, C] on the device the backend moves
@@ -94,20 +112,7 @@ def gather_frame(tile, height: int, mode: str = "interleaved", group=None, dst: 
         if ws is None:
             if len(_workspace) > 16:
                 _workspace.clear()
-            stacked = tile.new_empty((world,) + tuple(tile.shape))
-            lead, rest = tuple(tile.shape[:-3]), tuple(tile.shape[-2:])     # (B,) or (), and (W, C)
-            frame = tile.new_empty(lead + (height,) + rest)
-            n = height // world
-            b = len(lead)                                                    # 0 or 1: where the row axes start in `frame`
-            ranks_last = list(range(1, 1 + b)) + [0] + list(range(1 + b, stacked.ndim))   # [G, (B,) n, ...] -> [(B,) G, n, ...]
-            if mode == "bands":
-                dst_view, src_view = frame.view(lead + (world, n) + rest), stacked.permute(ranks_last)
-            elif mode == "interleaved":
-                dst_view, src_view = frame.view(lead + (n, world) + rest), stacked.permute(ranks_last).transpose(b, b + 1)
-            else:
-                raise ValueError(f"unknown partition mode {mode!r}")
-            # the per-rank views and the two sides of the copy are made once: this runs every frame
-            ws = ([stacked[r] for r in range(world)], frame, dst_view, src_view)
+            ws = _gather_workspace(tile, world, height, mode)
             _workspace[key] = ws
         parts, frame, dst_view, src_view = ws
         dist.gather(tile, parts, dst=dst, group=group)

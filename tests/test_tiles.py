@@ -143,3 +143,32 @@ def test_gather_of_a_batch_of_frames_gloo(mode, world):
 def test_single_process_batch_is_its_own_frames():
     tile = torch.arange(2 * 6 * 4 * 3, dtype=torch.uint8).view(2, 6, 4, 3)
     assert gather_frame(tile, 6) is tile
+
+
+def _check_workspace(device):
+    """The receive buffer and the strided copy of gather_frame without a process group: the per-rank views are filled
+    the way the collective fills them, the copy must put every rank's rows in place."""
+    from raytracing_amd.tiles import _gather_workspace
+    H, W, world = 24, 5, 4
+    rng = np.random.default_rng(3)
+    for mode in ("interleaved", "bands"):
+        for lead in ((), (3,)):
+            frames = rng.integers(0, 256, size=lead + (H, W, 3), dtype=np.uint8)
+            t0 = partition_rows(H, world, 0, mode)
+            tile = torch.empty(lead + (t0.nrows, W, 3), dtype=torch.uint8, device=device)
+            parts, frame, dst_view, src_view = _gather_workspace(tile, world, H, mode)
+            for r in range(world):
+                t = partition_rows(H, world, r, mode)
+                rows = frames[..., t.row0:t.row0 + t.nrows * t.stride:t.stride, :, :]
+                parts[r].copy_(torch.from_numpy(np.ascontiguousarray(rows)).to(device))
+            dst_view.copy_(src_view)
+            assert np.array_equal(frame.cpu().numpy(), frames), (mode, lead)
+
+
+def test_gather_workspace_places_rows_cpu():
+    _check_workspace("cpu")
+
+
+@pytest.mark.gpu
+def test_gather_workspace_places_rows_gpu():
+    _check_workspace("cuda:0")
