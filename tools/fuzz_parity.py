@@ -118,6 +118,12 @@ def run_cases(first, count, report=print, big=False, untimed=False, drift=None, 
                     nrows = int(prng.integers(1, (opt["height"] - row0 + stride - 1) // stride + 1))
                     part = c.render_rows(opt, seed=seed, row0=row0, nrows=nrows, row_stride=stride)
                     assert np.array_equal(part["bgr"], out["bgr"][row0::stride][:nrows]), ("rows", row0, nrows, stride)
+                    # the same rows as the first of two frames of one call; the second frame is the call with the next seed
+                    step = int(prng.integers(1, 1000))
+                    pair = c.render_rows(opt, seed=seed, row0=row0, nrows=nrows, row_stride=stride, frames=2, frame_seed_step=step)
+                    assert np.array_equal(pair["bgr"][0], part["bgr"]), ("frame 0 of 2", row0, nrows, stride)
+                    other = c.render_rows(opt, seed=seed + step, row0=row0, nrows=nrows, row_stride=stride)
+                    assert np.array_equal(pair["bgr"][1], other["bgr"]), ("frame 1 of 2", row0, nrows, stride, step)
                     # the trees of one pixel's samples, traced one by one, carry the colours the frame averaged
                     x, y = int(prng.integers(0, opt["width"])), int(prng.integers(0, opt["height"]))
                     S = opt["samples"] if opt["bounces"] > 1 else 1
