@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define T3D_ABI_VERSION 6
+#define T3D_ABI_VERSION 7
 
 enum {
     T3D_OK = 0,
@@ -276,9 +276,11 @@ int t3d_closest_hits(t3d_ctx* ctx, int n, const float* origins, const float* dir
                      int32_t* out_dirflag, float* out_normal);
 
 /*
- * Counters and per-kernel timings of the most recent t3d_render_rows_device call (of its last band
- * if the image was split into several): synchronises that call's stream first.  Lets a caller run
- * render calls asynchronously (stats == NULL) and still read kernel durations afterwards.
+ * Counters and timings of the most recent t3d_render_rows_device / _device_static / _async call: synchronises that
+ * call's stream first.  Lets a caller run render calls asynchronously (stats == NULL) and still read counters and
+ * kernel durations afterwards.  The counters and ms_device are those of the whole call, however many bands of rows
+ * it was cut into (an asynchronous call of several bands sums its bands' counters on the device); ms_k_level,
+ * ms_resolve and level_ms are those of its last band.
  * T3D_E_CAPACITY reports that the asynchronous call (any of its bands, or an earlier asynchronous call nobody
  * has asked about since) overflowed its node buffers (output invalid); see t3d_render_rows_device.
  * No counterpart in the reference (its timing is time.time() around the threads, T3DR.py:1119-1161).
@@ -293,6 +295,16 @@ int t3d_last_call_stats(t3d_ctx* ctx, t3d_stats* stats);
  * No counterpart in the reference.
  */
 int t3d_set_timing(t3d_ctx* ctx, int per_kernel);
+
+/*
+ * Launch graphs.  A band of rows asked for again through t3d_render_rows_device without `stats` -- same options, rows,
+ * output buffers and scene -- is replayed as one launch graph from its third request on (brute-force path): one
+ * submission instead of ten.  The seed is not part of what must be the same: a band asked for again with another
+ * opts->seed (the next frame of an animation) replays the same graph after the parameters of its first kernel node,
+ * the only launch that reads the seed, have been set anew.  The counters say how often each of that happened on this
+ * context (any pointer may be NULL).  No counterpart in the reference.
+ */
+int t3d_graph_counters(t3d_ctx* ctx, uint64_t* captured, uint64_t* replayed, uint64_t* reseeded);
 
 /*
  * How a launch with little work (a thin band, one rank's share of a frame) is cut up.  ADAPTIVE (default): into

@@ -12,13 +12,13 @@ import numpy as np
 from .flatten import FlatScene, Opts, SceneDesc, Stats, make_opts
 
 LIB_PATH = os.environ.get("T3D_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libt3d_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 SYMBOLS = ("t3d_abi_version", "t3d_device_count", "t3d_create", "t3d_destroy", "t3d_last_error",
            "t3d_upload_scene", "t3d_render_rows", "t3d_render_rows_device", "t3d_trace_pixel", "t3d_trace_ray",
            "t3d_closest_hits", "t3d_last_call_stats", "t3d_set_timing", "t3d_set_accel", "t3d_set_rounds", "t3d_set_cancel",
            "t3d_render_rows_async", "t3d_host_alloc", "t3d_host_free", "t3d_render_frame_multi",
-           "t3d_render_rows_device_static",
+           "t3d_render_rows_device_static", "t3d_graph_counters",
            "t3d_post_upscale_device", "t3d_post_denoise_device", "t3d_post_upscale", "t3d_post_denoise")
 
 
@@ -122,6 +122,8 @@ def load():
     lib.t3d_host_alloc.argtypes = [C.c_size_t, P(C.c_void_p)]
     lib.t3d_host_free.restype = C.c_int
     lib.t3d_host_free.argtypes = [C.c_void_p]
+    lib.t3d_graph_counters.restype = C.c_int
+    lib.t3d_graph_counters.argtypes = [C.c_void_p, P(C.c_uint64), P(C.c_uint64), P(C.c_uint64)]
     lib.t3d_set_cancel.restype = C.c_int
     lib.t3d_set_cancel.argtypes = [C.c_void_p, CANCEL_FN, C.c_void_p]
     lib.t3d_post_upscale_device.restype = C.c_int
@@ -334,6 +336,13 @@ class Context:
         """Device-pointer form (raw addresses); queued on ``stream`` (0: the context's) without waiting."""
         self._check(self._lib.t3d_post_denoise_device(self._h, C.c_void_p(in_ptr or None), height, width, kernel_size,
                                                       C.c_void_p(out_ptr or None), C.c_void_p(stream or None)), "t3d_post_denoise_device")
+
+    def graph_counters(self):
+        """Launch graphs of repeated bands on this context: how many were captured, how often one was replayed, and how
+        often a replay first had its seed changed (``t3d_graph_counters``)."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self._lib.t3d_graph_counters(self._h, C.byref(a), C.byref(b), C.byref(c)), "t3d_graph_counters")
+        return {"captured": a.value, "replayed": b.value, "reseeded": c.value}
 
     def set_timing(self, per_kernel: bool):
         """Per-kernel event timing on/off (on: ms_k_level / ms_resolve filled, a few us of idle per launch)."""

@@ -196,6 +196,15 @@ struct Counters {
     unsigned long long bvh_stat[T3D_SHARDS][8];  // per shard: nodes visited, triangle tests, sphere tests (one 64-byte line each)
 };
 
+// Counters of a whole render call that was cut into several bands and is not waited for: the two counter sets are used
+// in turn and a band's last kernel clears the set of the band before, so every band's sums are added up here by a
+// small kernel queued behind it (k_add_counters), and t3d_last_call_stats reads these instead of the last band's set.
+struct CallTotals {
+    unsigned long long rays[T3D_MAX_BOUNCES + 2];   // tree rays per level (level 0: the primary samples)
+    unsigned long long nodes[T3D_MAX_BOUNCES + 2];  // shaded nodes per level
+    unsigned long long bvh[8];                      // the bvh_stat columns
+};
+
 // ------------------------------------------------------------------------------------------------
 // small vector helpers
 // ------------------------------------------------------------------------------------------------
@@ -1483,6 +1492,23 @@ __global__ __launch_bounds__(T3D_BLOCK) void k_finish(RenderParams rp, const flo
     }
 }
 
+// One band's counters added to the totals of its call (one workgroup of 64 threads, queued behind the band).
+__global__ __launch_bounds__(64) void k_add_counters(const Counters* __restrict__ cnt, CallTotals* tot, int levels, unsigned long long n0) {
+    const int t = threadIdx.x;
+    if (t < levels) {
+        unsigned long long r = t == 0 ? n0 : 0ull, n = 0ull;
+        for (int sh = 0; sh < T3D_SHARDS; ++sh) {
+            if (t > 0) r += (unsigned long long)cnt->n_rays[t][sh].v;
+            n += (unsigned long long)cnt->n_nodes[t][sh].v;
+        }
+        tot->rays[t] += r; tot->nodes[t] += n;
+    } else if (t >= 32 && t < 40) {
+        unsigned long long a = 0ull;
+        for (int sh = 0; sh < T3D_SHARDS; ++sh) a += cnt->bvh_stat[sh][t - 32];
+        tot->bvh[t - 32] += a;
+    }
+}
+
 // closest hits for arbitrary rays (t3d_closest_hits); the second ray slot of every lane repeats the first
 __global__ __launch_bounds__(T3D_BLOCK) void k_closest(DevScene sc, GEO_PARAMS, int n, const float* __restrict__ origins,
                                                        const float* __restrict__ dirs, int lights, int back_cull,
@@ -1614,9 +1640,18 @@ struct t3d_ctx {
     hipStream_t last_stream = nullptr;
     // Launch graphs of repeated asynchronous bands: the same band (same options, rows, buffers, scene) asked for again
     // is one graph launch instead of ten kernel launches (0.1 ms of host time per call otherwise).
-    struct FrameGraph { bool valid = false; char key[320] = {}; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; uint64_t launches = 0; };
+    // The seed of the random numbers is not part of a graph's key: only the first kernel of a band reads it (the key of
+    // a pixel's random numbers is hashed once per primary ray and travels with the ray records), so a band asked for
+    // again with another seed -- the next frame of an animation -- replays the same graph after that one kernel node's
+    // parameters have been set anew (hipGraphExecKernelNodeSetParams).
+    struct FrameGraph {
+        bool valid = false; char key[320] = {}; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; uint64_t launches = 0;
+        hipGraphNode_t level0 = nullptr;   // the k_level launch of level 0; null: the graph serves its own seed only
+        uint32_t seed = 0;                 // the seed its level-0 node holds at the moment
+    };
     FrameGraph graphs[4];
     int graph_next = 0;
+    uint64_t graphs_captured = 0, graphs_replayed = 0, graphs_reseeded = 0;   // t3d_graph_counters
     char graph_miss[2][320] = {};   // bands that were launched kernel by kernel most recently: a graph is made at the second request
     int graph_miss_next = 0;
     bool graphs_enabled = true;
@@ -1640,6 +1675,13 @@ struct t3d_ctx {
     t3d_node* d_dbg = nullptr; int dbg_alloc = 0;   // node records of a single ray's tree (t3d_trace_pixel / t3d_trace_ray)
     unsigned char* static_scratch = nullptr;        // this device's copy of t3d_static_scratch (t3d_render_rows_device_static)
     bool counters_on_host = false;   // h_cnt holds (or is about to receive) the counters of the most recent band
+    // a call that is not waited for and is cut into several bands adds every band's counters up on the device
+    CallTotals* d_totals = nullptr;
+    CallTotals* h_totals = nullptr;   // pinned
+    int call_bands = 1;               // bands of the most recent render call (totals are kept when > 1 and nobody waited)
+    bool call_totals = false;         // d_totals holds the counters of the most recent call
+    uint64_t call_n0 = 0;             // its primary samples
+    hipEvent_t ev_call0 = nullptr;    // start of its first band (recorded when events are)
 };
 
 static thread_local std::string g_create_err;
@@ -1692,8 +1734,11 @@ extern "C" int t3d_create(int device, t3d_ctx** out) {
         hipMemset(c->d_cnt_pair[0], 0, sizeof(Counters)) != hipSuccess || hipMemset(c->d_cnt_pair[1], 0, sizeof(Counters)) != hipSuccess ||
         hipMalloc((void**)&c->d_fetch, sizeof(PaddedCount) * (T3D_MAX_BOUNCES + 2) * 2 * T3D_SHARDS) != hipSuccess ||
         hipHostMalloc((void**)&c->h_cnt, sizeof(Counters), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void**)&c->h_sticky, 64, hipHostMallocDefault) != hipSuccess)
+        hipHostMalloc((void**)&c->h_sticky, 64, hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void**)&c->d_totals, sizeof(CallTotals)) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_totals, sizeof(CallTotals), hipHostMallocDefault) != hipSuccess)
         return fail(T3D_E_NOMEM, "counter allocation failed");
+    if ((e = hipEventCreate(&c->ev_call0)) != hipSuccess) return fail(T3D_E_DEVICE, hipGetErrorString(e));
     c->h_sticky[0] = c->h_sticky[1] = 0;
     c->static_scratch = static_scratch_for(device, &e);   // the device is current
     if (!c->static_scratch) return fail(T3D_E_DEVICE, std::string("address of the static work array: ") + hipGetErrorString(e));
@@ -1734,6 +1779,9 @@ extern "C" void t3d_destroy(t3d_ctx* c) {
     hipFree(c->d_dbg);
     hipFree(c->d_cnt_pair[0]); hipFree(c->d_cnt_pair[1]); hipFree(c->d_fetch);
     if (c->h_cnt) hipHostFree(c->h_cnt);
+    hipFree(c->d_totals);
+    if (c->h_totals) hipHostFree(c->h_totals);
+    if (c->ev_call0) hipEventDestroy(c->ev_call0);
     for (auto& g : c->graphs) if (g.valid) { hipGraphExecDestroy(g.exec); hipGraphDestroy(g.graph); }
     hipFree(c->d_bgr); hipFree(c->d_rad); hipFree(c->d_prim); hipFree(c->d_prim_t);
     if (c->h_stage) hipHostFree(c->h_stage);
@@ -2105,12 +2153,14 @@ static int check_opts(t3d_ctx* c, const t3d_opts* o, int row0, int nrows) {
     return T3D_OK;
 }
 
-// Counters and event timings of the most recent band; the stream must have been synchronised.
-static void fill_stats(t3d_ctx* c, t3d_stats* stats) {
+// Counters and event timings of the most recent band -- or, with `whole_call`, the counters of every band of the most
+// recent call as k_add_counters summed them (timings: the whole call's device time, the last band's per-kernel times);
+// the stream must have been synchronised.
+static void fill_stats(t3d_ctx* c, t3d_stats* stats, bool whole_call = false) {
     const int levels = c->last_levels;
     const int n_ev = c->last_timed ? levels + 2 : 2;
     float ms = 0;
-    if (c->last_events) hipEventElapsedTime(&ms, c->ev[0], c->ev[n_ev - 1]);
+    if (c->last_events) hipEventElapsedTime(&ms, whole_call ? c->ev_call0 : c->ev[0], c->ev[n_ev - 1]);
     stats->ms_device += ms;
     if (c->last_timed) {
         for (int d = 0; d < levels; ++d) {
@@ -2121,37 +2171,40 @@ static void fill_stats(t3d_ctx* c, t3d_stats* stats) {
         hipEventElapsedTime(&ms, c->ev[levels], c->ev[n_ev - 1]);
         stats->ms_resolve += ms;
     }
+    CallTotals sums{};
+    if (whole_call) sums = *c->h_totals;
+    else {
+        for (int d = 0; d < levels; ++d) {
+            if (d == 0) sums.rays[0] = c->last_n0;
+            for (int sh = 0; sh < T3D_SHARDS; ++sh) {
+                if (d > 0) sums.rays[d] += (uint64_t)c->h_cnt->n_rays[d][sh].v;
+                sums.nodes[d] += (uint64_t)c->h_cnt->n_nodes[d][sh].v;
+            }
+        }
+        for (int sh = 0; sh < T3D_SHARDS; ++sh) for (int k = 0; k < 8; ++k) sums.bvh[k] += c->h_cnt->bvh_stat[sh][k];
+    }
+    const uint64_t n0 = whole_call ? c->call_n0 : c->last_n0;
     uint64_t rays = 0, nodes = 0;
     for (int d = 0; d < levels; ++d) {
-        uint64_t lr = d == 0 ? c->last_n0 : 0, ln = 0;
-        for (int sh = 0; sh < T3D_SHARDS; ++sh) {
-            if (d > 0) lr += (uint64_t)c->h_cnt->n_rays[d][sh].v;
-            ln += (uint64_t)c->h_cnt->n_nodes[d][sh].v;
-        }
-        rays += lr; nodes += ln;
-        stats->level_rays[d] += lr; stats->level_nodes[d] += ln;
+        rays += sums.rays[d]; nodes += sums.nodes[d];
+        stats->level_rays[d] += sums.rays[d]; stats->level_nodes[d] += sums.nodes[d];
     }
     uint64_t shadow = nodes * (uint64_t)c->sc.n_lights;
     uint64_t q = rays + shadow;
-    stats->rays_api += c->last_n0 + shadow;
+    stats->rays_api += n0 + shadow;
     stats->queries += q;
     stats->trace_queries += rays;
     stats->shadow_queries += shadow;
-    uint64_t culled = 0;
-    for (int sh = 0; sh < T3D_SHARDS; ++sh) culled += c->h_cnt->bvh_stat[sh][4];
+    const uint64_t culled = sums.bvh[4];
     stats->shadow_culled += culled;
     if (c->use_bvh) {
-        uint64_t nv = 0, tt = 0, stt = 0;
-        for (int sh = 0; sh < T3D_SHARDS; ++sh) {
-            nv += c->h_cnt->bvh_stat[sh][0]; tt += c->h_cnt->bvh_stat[sh][1]; stt += c->h_cnt->bvh_stat[sh][2];
-            stats->bvh_deep_pushes += c->h_cnt->bvh_stat[sh][3];
-        }
-        stats->aabb_tests += 4 * nv;  // every record visited holds four boxes
-        stats->tri_tests += tt;
-        stats->sphere_tests += stt;
+        stats->bvh_deep_pushes += sums.bvh[3];
+        stats->aabb_tests += 4 * sums.bvh[0];  // every record visited holds four boxes
+        stats->tri_tests += sums.bvh[1];
+        stats->sphere_tests += sums.bvh[2];
     } else {
         stats->tri_tests += (q - culled) * (uint64_t)c->sc.n_tris;
-        stats->sphere_tests += (q - culled) * (uint64_t)c->sc.n_spheres - (c->last_lights ? 0 : c->last_n0 * (uint64_t)c->n_light_objs);
+        stats->sphere_tests += (q - culled) * (uint64_t)c->sc.n_spheres - (c->last_lights ? 0 : n0 * (uint64_t)c->n_light_objs);
     }
     stats->nodes += nodes;  // shaded nodes only; emitter leaves are folded into their parents
 #ifdef T3D_COUNT_GROUPS
@@ -2163,8 +2216,8 @@ static void fill_stats(t3d_ctx* c, t3d_stats* stats) {
                 g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
     }
 #endif
-    stats->launches += c->last_launches;
-    stats->n_k_level += (uint64_t)levels;
+    stats->launches += (whole_call ? (uint64_t)c->call_bands : 1) * c->last_launches;
+    stats->n_k_level += (uint64_t)levels * (whole_call ? (uint64_t)c->call_bands : 1);
 }
 
 // Trace one band whose outputs are device pointers, with the work buffers `w` (grown as needed unless `fixed_work`:
@@ -2267,15 +2320,40 @@ static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int fra
     bool capturing = false;
     hipStream_t ls = st;   // where the brute-force path's kernels are queued: the call's stream, or the recording stream
     t3d_ctx::FrameGraph* slot = nullptr;
+    // level 0 of the brute-force path: the launch a graph re-parameterises for another seed
+    void* level0_fn = nullptr;
+    const int level0_grid = single ? 0 : trace_blocks_for(n0) * T3D_WAVES;
+    RayRec* level0_in = w.rays[0];
+    RayRec* level0_out = w.rays[1];
+    int level0_depth = 0;
     if (graphable) {
         memset(key, 0, sizeof key);
-        memcpy(key, &rp, sizeof rp);
+        RenderParams key_rp = rp;
+        key_rp.seed = 0;
+        memcpy(key, &key_rp, sizeof key_rp);
         const void* ptrs[12] = {d_bgr, d_rad, d_prim, d_prim_t, c->d_cnt, next_cnt, w.rays[0], w.rays[1], w.pool.c, w.pool.li,
                                 w.sample_color, (const void*)(uintptr_t)((c->scene_gen << 32) ^ w.gen)};
         memcpy(key + sizeof rp, ptrs, sizeof ptrs);
         for (auto& g : c->graphs)
-            if (g.valid && memcmp(g.key, key, sizeof key) == 0) {
+            if (g.valid && memcmp(g.key, key, sizeof key) == 0 && (g.seed == rp.seed || g.level0)) {
+                if (g.seed != rp.seed) {
+                    // another frame of the same band: the level-0 node gets this call's parameters (only the seed differs)
+                    level0_fn = pairs ? (void*)k_level<true, 1, true> : (void*)k_level<true, 1, false>;
+                    void* kargs[] = {(void*)&c->sc, (void*)&planes, (void*)&pfirst, (void*)&uv, (void*)&sph, (void*)&c->sc.lights, (void*)&rp,
+                                     (void*)&level0_depth, (void*)&level0_in, (void*)&level0_out, (void*)&w.pool, (void*)&c->d_cnt, (void*)&out};
+                    hipKernelNodeParams np{};
+                    np.func = level0_fn; np.gridDim = dim3(level0_grid); np.blockDim = dim3(64); np.sharedMemBytes = 0;
+                    np.kernelParams = kargs; np.extra = nullptr;
+                    if (hipGraphExecKernelNodeSetParams(g.exec, g.level0, &np) != hipSuccess) {
+                        (void)hipGetLastError();
+                        g.level0 = nullptr;      // this runtime cannot do it: the graph keeps serving its own seed
+                        break;
+                    }
+                    g.seed = rp.seed;
+                    c->graphs_reseeded++;
+                }
                 HIPCHK(c, hipGraphLaunch(g.exec, st));
+                c->graphs_replayed++;
                 launches = g.launches;
                 goto issued;
             }
@@ -2391,6 +2469,23 @@ static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int fra
         memcpy(slot->key, key, sizeof key);
         slot->launches = launches;
         slot->valid = true;
+        slot->seed = rp.seed;
+        slot->level0 = nullptr;
+        {
+            // the one launch that reads the seed is the first of the band: the graph's only root
+            size_t n_root = 0;
+            hipGraphNode_t root = nullptr;
+            hipGraphNodeType ty;
+            hipKernelNodeParams np{};
+            const void* want = pairs ? (const void*)k_level<true, 1, true> : (const void*)k_level<true, 1, false>;
+            if (hipGraphGetRootNodes(slot->graph, nullptr, &n_root) == hipSuccess && n_root == 1 &&
+                hipGraphGetRootNodes(slot->graph, &root, &n_root) == hipSuccess && hipGraphNodeGetType(root, &ty) == hipSuccess &&
+                ty == hipGraphNodeTypeKernel && hipGraphKernelNodeGetParams(root, &np) == hipSuccess && np.func == want &&
+                np.gridDim.x == (unsigned)level0_grid)
+                slot->level0 = root;
+            (void)hipGetLastError();
+        }
+        c->graphs_captured++;
         HIPCHK(c, hipGraphLaunch(slot->exec, st));
     }
 issued:
@@ -2429,6 +2524,22 @@ static int take_sticky(t3d_ctx* c) {
     return T3D_OK;
 }
 
+// A render call that is not waited for (no stats) and takes several bands keeps whole-call counters on the device:
+// cleared here, every band's added by k_add_counters behind it, read by t3d_last_call_stats.
+static int call_totals_begin(t3d_ctx* c, hipStream_t st, bool keep) {
+    c->call_bands = 1; c->call_totals = false; c->call_n0 = 0;
+    if (!keep) return T3D_OK;
+    HIPCHK(c, hipMemsetAsync(c->d_totals, 0, sizeof(CallTotals), st));
+    if (c->timing) HIPCHK(c, hipEventRecord(c->ev_call0, st));
+    return T3D_OK;
+}
+static int call_totals_add(t3d_ctx* c, hipStream_t st, int levels, size_t n0, int bands_done) {
+    hipLaunchKernelGGL(k_add_counters, dim3(1), dim3(64), 0, st, c->d_cnt, c->d_totals, levels, (unsigned long long)n0);
+    HIPCHK(c, hipGetLastError());
+    c->call_n0 += n0; c->call_bands = bands_done; c->call_totals = true;
+    return T3D_OK;
+}
+
 extern "C" int t3d_render_rows_device(t3d_ctx* c, const t3d_opts* o, int row0, int nrows, uint8_t* bgr_device,
                                       float* radiance_device, int32_t* primary_device, float* primary_t_device,
                                       void* stream, t3d_stats* stats) {
@@ -2455,6 +2566,9 @@ extern "C" int t3d_render_rows_device(t3d_ctx* c, const t3d_opts* o, int row0, i
     // a level holds at most 2^bounces rays per sample; a band of few samples is worked on by few waves, whose
     // rays all land in those waves' shards, so the bound on the factor counts every shard
     const int factor_limit = (1 << o->bounces) * T3D_SHARDS;
+    const bool keep_totals = !stats && band < vrows;
+    if ((rc = call_totals_begin(c, st, keep_totals)) != T3D_OK) return rc;
+    int bands_done = 0;
     for (int r = 0; r < vrows;) {
         if (c->cancel_cb && c->cancel_cb(c->cancel_user)) { c->last_valid = false; c->err = "render cancelled by the caller's cancel callback"; return T3D_E_CANCELLED; }
         int nb = band < vrows - r ? band : vrows - r;
@@ -2477,6 +2591,7 @@ extern "C" int t3d_render_rows_device(t3d_ctx* c, const t3d_opts* o, int row0, i
                 continue;
             }
             if (rc) { if (rc == T3D_E_CAPACITY) c->err = "trace tree does not fit the node buffers"; return rc; }
+            if (keep_totals && (rc = call_totals_add(c, st, levels, (size_t)nb * o->width * S, ++bands_done)) != T3D_OK) return rc;
             if (stats) {
                 uint64_t* dst = &stats->rays_api; const uint64_t* src = &band_stats.rays_api;
                 for (int k = 0; k < T3D_STATS_N_COUNTERS; ++k) dst[k] += src[k];
@@ -2554,6 +2669,11 @@ extern "C" int t3d_render_rows_device_static(t3d_ctx* c, const t3d_opts* o, int 
     const int vrows = nrows * (o->frames > 1 ? o->frames : 1);   // the rows of the call, all its frames one after the other
     int band = 1;   // the largest number of rows whose optimistic working set (two rays per sample and level) fits
     for (int lo = 1, hi = vrows; lo <= hi;) { const int mid = lo + (hi - lo) / 2; if (fits(mid, factor0)) { band = mid; lo = mid + 1; } else hi = mid - 1; }
+    const bool keep_totals = !stats && band < vrows;
+    if ((rc = call_totals_begin(c, st, keep_totals)) != T3D_OK) return rc;
+    int bands_done = 0;
+    // a level holds at most 2^bounces rays per sample, and the rays of a band of few samples land in few shards
+    const int factor_limit = (1 << o->bounces) * T3D_SHARDS;
     for (int r = 0; r < vrows;) {
         if (c->cancel_cb && c->cancel_cb(c->cancel_user)) { c->last_valid = false; c->err = "render cancelled by the caller's cancel callback"; return T3D_E_CANCELLED; }
         int nb = band < vrows - r ? band : vrows - r;
@@ -2568,10 +2688,15 @@ extern "C" int t3d_render_rows_device_static(t3d_ctx* c, const t3d_opts* o, int 
             if (rc == T3D_E_CAPACITY) {
                 // only a call with stats gets here (it has waited for the band): fewer rows, and for a single row a larger factor
                 if (nb > 1) { nb = (nb + 1) / 2; continue; }
-                factor *= 2;
+                // a single row: the first factor that really gives more room than the capacity just tried (narrow rows sit
+                // on the minimum capacity, which doubling the factor would not leave for many rounds)
+                const size_t tried = cap_for(row_samples, factor);
+                while (factor < factor_limit && cap_for(row_samples, factor) <= tried) factor *= 2;
+                if (cap_for(row_samples, factor) <= tried) { c->err = "t3d_render_rows_device_static: trace tree does not fit the node buffers"; return T3D_E_CAPACITY; }
                 continue;
             }
             if (rc) return rc;
+            if (keep_totals && (rc = call_totals_add(c, st, levels, (size_t)nb * row_samples, ++bands_done)) != T3D_OK) return rc;
             if (stats) {
                 uint64_t* dst = &stats->rays_api; const uint64_t* src = &band_stats.rays_api;
                 for (int k = 0; k < T3D_STATS_N_COUNTERS; ++k) dst[k] += src[k];
@@ -2618,14 +2743,23 @@ extern "C" int t3d_last_call_stats(t3d_ctx* c, t3d_stats* stats) {
         HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, c->last_stream));
         c->counters_on_host = true;
     }
+    // a call of several bands: the sums of all of them (k_add_counters); d_cnt holds its last band only
+    if (c->call_totals) HIPCHK(c, hipMemcpyAsync(c->h_totals, c->d_totals, sizeof(CallTotals), hipMemcpyDeviceToHost, c->last_stream));
     HIPCHK(c, hipStreamSynchronize(c->last_stream));
     memset(stats, 0, sizeof *stats);
-    // the sticky words cover every band of the call (and any earlier asynchronous call nobody has asked about), the
-    // counters only its last band
+    // the sticky words cover every band of the call (and any earlier asynchronous call nobody has asked about)
     int rc = take_sticky(c);
     if (rc != T3D_OK) return rc;
     if (c->h_cnt->overflow) { c->err = "trace tree did not fit the node buffers"; return T3D_E_CAPACITY; }
-    fill_stats(c, stats);
+    fill_stats(c, stats, c->call_totals);
+    return T3D_OK;
+}
+
+extern "C" int t3d_graph_counters(t3d_ctx* c, uint64_t* captured, uint64_t* replayed, uint64_t* reseeded) {
+    if (!c) return T3D_E_INVALID;
+    if (captured) *captured = c->graphs_captured;
+    if (replayed) *replayed = c->graphs_replayed;
+    if (reseeded) *reseeded = c->graphs_reseeded;
     return T3D_OK;
 }
 
@@ -2873,6 +3007,7 @@ static int trace_single(t3d_ctx* c, const t3d_opts* o, const RenderParams& singl
     // The whole tree lives in one queue shard (render_band uses a single shard and a single workgroup for it), and a
     // level of it holds at most 2^bounces rays: that is all the capacity a level needs.
     const int factor = 1 << o->bounces;
+    c->call_totals = false; c->call_bands = 1;
     rc = render_band(c, c->single_work, o, row, 1, 0, 1, factor, nullptr, nullptr, nullptr, nullptr, c->stream, &st, &single, d_dbg, dbg_cap);
     int n = 0;
     if (!rc) {

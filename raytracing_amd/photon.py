@@ -427,6 +427,9 @@ class Photon:
                 slot[1] = digest
                 self.uploads += 1
         self._flat, self._baked = flat, True
+        if digest != self._uploaded_digest:
+            # the context that serves traces / picking still holds an older scene: _prepare uploads this one on first use
+            self._uploaded_digest = None
         native_opts = self._native_options()
         seed = int(opts.get("seed", 0))
         progress = ThreadsProgress(callback=progressCallback or (lambda table, key, total: None), total=height * width)
@@ -498,6 +501,14 @@ class Photon:
                     raise
                 early = None                          # the trees outgrew the buffers: render again, checked
         else:
+            if early:
+                # the frame started on the old device scene is thrown away -- and with it whatever it has to report: an
+                # overflow of its node buffers must not be handed to the checked call below as if it were its own
+                try:
+                    ctx.last_call_stats()
+                except _native.NativeError as e:
+                    if e.code != _native.E_CAPACITY:
+                        raise
             early = None
         if not early:
             if not plain:

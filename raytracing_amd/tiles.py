@@ -79,18 +79,20 @@ def _gather_workspace(tile, world: int, height: int, mode: str):
     return [stacked[r] for r in range(world)], frame, dst_view, src_view
 
 
-def gather_frame(tile, height: int, mode: str = "interleaved", group=None, dst: int = 0, slot: int = 0):
+def gather_frame(tile, height: int, mode: str = "interleaved", group=None, dst: int = 0, slot: int = 0, collective_always: bool = False):
     """Collect every rank's tile on rank ``dst`` and return the assembled frame there (``None`` on
     the other ranks).  ``tile`` is a torch tensor [H/G, W, C] on the device the backend moves
     (GPU for nccl/RCCL, CPU for gloo) -- or [B, H/G, W, C], the tiles of B frames rendered by one call: they
     travel in one collective and come back as frames [B, H, W, C].  Single-process use returns the tile's own
     frame.  The returned frame is a buffer that the next call with the same shapes, stream and ``slot``
     overwrites: a caller that keeps several frames in flight gives each chain a slot (and, on a GPU, a stream)
-    of its own."""
+    of its own.  ``collective_always``: a group of one rank goes through the collective and the strided copy as well
+    (the whole several-rank code path, exercised on a one-GPU box) instead of being answered from the tile."""
     import torch.distributed as dist
 
     batched = tile.ndim == 4
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    grouped = dist.is_available() and dist.is_initialized()
+    if not grouped or (dist.get_world_size(group) == 1 and not collective_always):
         if tile.shape[-3] == height:
             return tile                                                      # one rank: the tile is the frame
         if batched:

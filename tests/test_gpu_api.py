@@ -293,6 +293,126 @@ def test_photon_render_on_several_gpus():
     assert multi.uploads == 4
 
 
+def _glass_onion(T3DE):
+    """Six nested glass spheres: trace trees that double with every bounce."""
+    from raytracing_amd.scene import Camera, Light, Material, Scale, Scene, Shader, Sphere, Vec3, RGB
+    s = Scene()
+    Camera(s, position=Vec3(0, 0, -4), length=30)
+    for r in (3.0, 2.6, 2.2, 1.8, 1.4, 1.0):
+        b = Sphere(s, position=Vec3(0, 0, 6))
+        b.scale = Scale(2 * r, 2 * r, 2 * r)
+        b.setShader(Shader(color=RGB(200, 220, 250), roughness=0.0, reflectivity=0.5))
+        b.material = Material(ior=1.3)
+    Light(s, position=Vec3(4, 5, -2), strength=1.0)
+    return s
+
+
+def test_photon_render_discards_the_overflow_of_a_frame_it_threw_away():
+    """render() starts the device on the scene it uploaded last time before it knows whether the scene changed.  When it
+    did change, that frame is thrown away -- and an overflow of ITS node buffers (new options: deeper trees) must not be
+    reported by the checked call that follows for the new scene."""
+    import T3DE
+    import T3DR
+    s = _glass_onion(T3DE)
+    photon = T3DR.Photon(s, {"width": 24, "height": 16, "bounces": 1, "samples": 2, "seed": 5})
+    photon.render()                                              # small buffers, scene on the device
+    photon.options["bounces"] = 9                                # the speculative frame will overflow them ...
+    light = next(o for o in s.objects if o.type == "light")
+    light.position = T3DE.Vec3(3, 5, -2)                         # ... and is not wanted: the scene changed
+    deep = photon.render()
+    assert photon.uploads == 2
+    fresh = T3DR.Photon(s, {"width": 24, "height": 16, "bounces": 9, "samples": 2, "seed": 5}).render()
+    assert np.array_equal(deep.imageAs("np"), fresh.imageAs("np")) and deep.rays == fresh.rays
+
+
+def test_traces_follow_scene_edits_between_renders_on_several_gpus():
+    """The context that serves traces / picking is not one of the several-GPU path's: after an edit and another render on
+    several contexts it must be given the edited scene too."""
+    import T3DE
+    import T3DR
+    scene = T3DE.Scene.fromJSON(scene_path("cornellScene.json"))
+    opts = {"width": 64, "height": 48, "bounces": 2, "samples": 2, "seed": 3}
+    multi = T3DR.Photon(scene, dict(opts, gpus=2, devices=[0, 0]))
+    before = multi.render()
+    hit_before = before.traces[(20, 30)][0].collisionInfo["point"]
+    ball = next(o for o in scene.objects if o.type == "sphere")
+    ball.position = T3DE.Vec3(ball.position.x + 0.9, ball.position.y + 0.4, ball.position.z)
+    after = multi.render()
+    single = T3DR.Photon(scene, dict(opts))
+    want = single.render()
+    assert np.array_equal(after.imageAs("np"), want.imageAs("np"))
+    moved = 0
+    for key in [(20, 30), (14, 33), (25, 36), (40, 20)]:
+        a, b = after.traces[key][0], want.traces[key][0]
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert a.collisionInfo["object"].id == b.collisionInfo["object"].id
+            assert np.allclose([*a.collisionInfo["point"]], [*b.collisionInfo["point"]], atol=1e-5)
+    pick = multi.getFirstCollision(multi.getRay(multi.pixelToVector(20, 30)), True, False)
+    ref = single.getFirstCollision(single.getRay(single.pixelToVector(20, 30)), True, False)
+    assert (pick["object"].id, pick["t"]) == (ref["object"].id, ref["t"])
+    assert hit_before is not None
+
+
+@pytest.mark.parametrize("accel", ["brute", "lbvh"])
+def test_counters_of_an_unwaited_call_cover_all_its_bands(accel, monkeypatch):
+    """A call that is not waited for and is cut into several bands reports, through t3d_last_call_stats, the counters of
+    all its bands (summed on the device), not those of the last one: the asynchronous host render, the device-pointer
+    call without stats (also through the static work array), and the frame on several contexts."""
+    import torch
+    from raytracing_amd import _native
+    flat = flat_for("config2_cornell_light.json")
+    opt = dict(width=96, height=54, bounces=3, samples=2)
+    monkeypatch.setenv("T3D_MEM_BUDGET_MB", "1")       # a few rows per band
+    keys = ("queries", "rays_api", "nodes", "shadow_queries", "trace_queries", "shadow_culled")
+    if accel == "brute":      # through the hierarchy the number of tests depends on which rays share a wave, i.e. on the buffer sizes
+        keys += ("tri_tests", "sphere_tests")
+    ctxs = [_native.Context(0) for _ in range(3)]
+    try:
+        for c in ctxs:
+            c.set_accel(accel)
+            c.upload(flat)
+        want = ctxs[0].render_rows(opt, seed=2)
+        assert want["stats"]["n_k_level"] >= 4 * 3, "the frame was meant to be cut into several bands"
+        img = _native.pinned_image((54, 96, 3))
+        for attempt in range(4):                       # an unchecked call may first have to learn the capacity it needs
+            ctxs[0].render_rows_async(opt, 2, 0, 54, img)
+            try:
+                st = ctxs[0].last_call_stats()
+                break
+            except _native.NativeError as e:
+                assert e.code == _native.E_CAPACITY
+        assert np.array_equal(img, want["bgr"])
+        for k in keys + ("n_k_level",):
+            assert st[k] == want["stats"][k], k
+        assert list(st["level_rays"]) == list(want["stats"]["level_rays"]) and list(st["level_nodes"]) == list(want["stats"]["level_nodes"])
+        assert st["ms_device"] > 0
+        for static in (False, True):
+            out = torch.zeros((54, 96, 3), dtype=torch.uint8, device="cuda:0")
+            for attempt in range(4):
+                ctxs[0].render_rows_device(opt, 2, 0, 54, out.data_ptr(), want_stats=False, static=static)
+                try:
+                    st = ctxs[0].last_call_stats()
+                    break
+                except _native.NativeError as e:
+                    assert e.code == _native.E_CAPACITY
+            assert np.array_equal(out.cpu().numpy(), want["bgr"])
+            for k in keys:
+                assert st[k] == want["stats"][k], (k, static)
+        # a one-band call afterwards reports its own counters again
+        small = ctxs[0].render_rows(dict(opt, height=2), seed=2)
+        ctxs[0].render_rows_async(dict(opt, height=2), 2, 0, 2, _native.pinned_image((2, 96, 3)))
+        assert ctxs[0].last_call_stats()["queries"] == small["stats"]["queries"]
+        frame = _native.pinned_image((54, 96, 3))
+        mst = _native.render_frame_multi(ctxs, opt, 2, out=frame)
+        assert np.array_equal(frame, want["bgr"])
+        for k in keys:
+            assert mst[k] == want["stats"][k], k
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def test_single_ray_trees_with_many_lights_need_little_memory(gpu_ctx, oracle_mod):
     """The tree of one pixel at 12 bounces in a scene whose 968 emissive faces are 968 lights: the work set of a
     single ray is sized by its tree (at most 2^12 nodes a level), not by a band of rows."""
@@ -314,44 +434,123 @@ def test_single_ray_trees_with_many_lights_need_little_memory(gpu_ctx, oracle_mo
         assert np.allclose(list(n.color), want[n.heap]["color"], atol=0.05)
 
 
-def _run_bench_ranks(n, extra):
+def test_a_replayed_launch_graph_takes_the_seed_of_every_call():
+    """The frames of an animation: the same band asked for again and again, every time with another seed.  From the third
+    request on the band is one launch graph, and the graph's first kernel node -- the only launch that reads the seed -- is
+    given each call's parameters before the replay.  Every frame must equal the frame a checked (ungraphed) call renders."""
+    import torch
+    from raytracing_amd import _native
+    flat = flat_for("config2_cornell_light.json")
+    opt = dict(width=96, height=64, bounces=3, samples=1)
+    ctx = _native.Context(0)
+    try:
+        ctx.upload(flat)
+        want = [ctx.render_rows(opt, seed=s)["bgr"] for s in range(9)]
+        assert not np.array_equal(want[0], want[1])
+        ctx.set_timing(False)
+        out = torch.zeros((64, 96, 3), dtype=torch.uint8, device="cuda:0")
+        stream = torch.cuda.Stream()
+        before = ctx.graph_counters()
+        order = [0, 0, 0, 0, 0, 0, 1, 2, 2, 3, 8, 0, 5, 5, 4]
+        for s in order:
+            ctx.render_rows_device(opt, s, 0, 64, out.data_ptr(), stream=stream.cuda_stream, want_stats=False)
+            stream.synchronize()
+            assert np.array_equal(out.cpu().numpy(), want[s]), s
+        after = ctx.graph_counters()
+        assert after["captured"] - before["captured"] >= 1
+        assert after["replayed"] - before["replayed"] >= 8, after
+        assert after["reseeded"] - before["reseeded"] >= 6, after     # 0->1, 1->2, 2->3, 3->8, 8->0, 0->5, 5->4 on one graph or two
+        # several frames per call: the seed of frame f is seed + f * step, and the first seed is what a replay changes
+        out2 = torch.zeros((2, 64, 96, 3), dtype=torch.uint8, device="cuda:0")
+        for s in (0, 0, 0, 0, 0, 0, 3, 6, 1):
+            ctx.render_rows_device(opt, s, 0, 64, out2.data_ptr(), stream=stream.cuda_stream, want_stats=False, frames=2, frame_seed_step=2)
+            stream.synchronize()
+            got = out2.cpu().numpy()
+            assert np.array_equal(got[0], want[s]) and np.array_equal(got[1], want[s + 2]), s
+        ctx.last_call_stats()
+    finally:
+        ctx.close()
+
+
+def _run_bench_ranks(n, extra, steps=3, warmup=1, timeout=280):
     import json
     import os
     import subprocess
     import sys
     from test_tiles import _free_port
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1"] + extra
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=root)
+    launcher = [sys.executable]
+    if n > 1:
+        launcher += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+                     "--master-port", str(_free_port())]
+    cmd = launcher + [os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", str(steps), "--warmup", str(warmup)] + extra
+    env = dict(os.environ, MASTER_PORT=str(_free_port())) if n == 1 else None
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     return json.loads(lines[0])
 
 
+FRAME_QUERIES = 17874992     # closest-hit queries of the benchmark frame with seed 0, in the reference's count
+
+
+def _check_frame_counts(d):
+    """Every frame of the run has its own seed, so the per-frame counts are averages: near those of the frame with seed 0,
+    and the traced and the untraced queries add up to the reference's count."""
+    cfg = d["config"]
+    assert abs(cfg["reference_queries_per_frame"] - FRAME_QUERIES) < 0.002 * FRAME_QUERIES
+    assert abs(cfg["queries_per_frame"] + cfg["shadow_rays_answered_untraced_per_frame"] - cfg["reference_queries_per_frame"]) < 0.5
+
+
 def test_bench_with_two_ranks_rehearsed_on_one_gpu():
     """bench.py as the driver starts it for N > 1 -- torch.distributed.run, one process per rank, interleaved rows,
     several frames in flight per rank, a gather per frame, counters summed, time the maximum over ranks -- with the
-    gloo backend, so that two ranks can share the one GPU a test box has (RCCL refuses that)."""
+    gloo backend, so that two ranks can share the one GPU a test box has (RCCL refuses that).  bench.py itself compares
+    every frame of every chain's last call with the tile rendered alone and raises on a difference."""
     d = _run_bench_ranks(2, ["--dist-backend", "gloo"])
-    assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["scaling"] == "strong" and d["steps"] == 3
+    assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["steps"] == 3
+    assert d["scaling"] == "strong (batched, 2 frames per call)"
     assert d["config"]["partition"] == "interleaved rows x2" and "gloo" in d["config"]["collective"]
-    assert d["config"]["reference_queries_per_frame"] == 17874992          # both halves of the frame, summed over the ranks
-    assert d["config"]["queries_per_frame"] + d["config"]["shadow_rays_answered_untraced_per_frame"] == 17874992
+    _check_frame_counts(d)
     assert d["value"] > 0 and "cpu_baseline" not in d          # the CPU baseline is a one-rank field
     # a call carries a rank's rows of two frames; the three timed frames are one such call and one call of a single frame
     assert d["config"]["frames_per_call"] == 2 and d["config"]["frames_in_flight"] == 2 * d["config"]["calls_in_flight"]
+    # beside the batched figure: one frame per call, the latency of one frame, and the whole frame on one GPU alone
+    sf = d["single_frame"]
+    assert sf["frames_per_call"] == 1 and sf["ms_per_frame"] > 0 and sf["frame_latency_ms"] > 0 and sf["one_gpu_whole_frame_alone_ms"] > 0
+    assert d["ms_per_step_varying_seed"] == d["ms_per_step"] and d["ms_per_step_fixed_seed"] > 0
 
 
 def test_bench_with_four_ranks_rehearsed_on_one_gpu():
-    """Four ranks: a call carries a rank's 270 rows of four frames, whose pixel tiles (eight rows high) straddle the frames;
-    bench.py itself compares every frame of every chain's last call with the tile rendered alone and raises on a difference."""
-    d = _run_bench_ranks(4, ["--dist-backend", "gloo"])
+    """Four ranks: a call carries a rank's 270 rows of four frames, whose pixel tiles (eight rows high) straddle the frames."""
+    d = _run_bench_ranks(4, ["--dist-backend", "gloo", "--no-secondary"])
     assert d["n_gpus"] == 4 and d["config"]["partition"] == "interleaved rows x4" and d["steps"] == 3
     assert d["config"]["frames_per_call"] == 4 and d["config"]["calls_in_flight"] == 4 and d["config"]["frames_in_flight"] == 16
-    assert d["config"]["reference_queries_per_frame"] == 17874992
-    assert d["config"]["queries_per_frame"] + d["config"]["shadow_rays_answered_untraced_per_frame"] == 17874992
+    _check_frame_counts(d)
+    assert "single_frame" not in d
+
+
+def test_bench_with_eight_ranks_and_the_drivers_arguments():
+    """The command the driver runs on an 8-GPU node, argument for argument (20 steps after 5 of warm-up: two calls of eight
+    frames and one of four), with eight ranks sharing this box's GPU over gloo."""
+    d = _run_bench_ranks(8, ["--dist-backend", "gloo"], steps=20, warmup=5, timeout=420)
+    assert d["n_gpus"] == 8 and d["steps"] == 20 and d["warmup"] == 5 and d["config"]["partition"] == "interleaved rows x8"
+    assert d["scaling"] == "strong (batched, 8 frames per call)"
+    assert d["config"]["frames_per_call"] == 8 and d["config"]["calls_in_flight"] == 4
+    _check_frame_counts(d)
+    assert d["single_frame"]["ms_per_frame"] > 0 and d["single_frame"]["speedup_vs_one_gpu_frame_alone"] > 0
+    assert abs(d["value"] * d["ms_per_step"] * 1e3 - d["config"]["queries_per_frame"]) < 1e-3 * d["config"]["queries_per_frame"]
+
+
+def test_bench_gather_in_a_one_rank_rccl_group():
+    """One rank, but in a real RCCL process group: every frame of every chain goes through dist.gather and the strided copy
+    on its chain's stream while the other chains' launch graphs replay -- the several-rank code path, collective library
+    and its watchdog thread included, on a one-GPU box.  bench.py checks the gathered frames against the tiles."""
+    d = _run_bench_ranks(1, ["--one-rank-group", "--no-cpu-baseline"], steps=24, warmup=2)
+    assert d["n_gpus"] == 1 and d["config"]["collective"] == "RCCL gather in a group of one rank"
+    assert d["config"]["calls_in_flight"] == 3 and d["scaling"] == "strong"
+    _check_frame_counts(d)
 
 
 def test_bench_with_two_ranks_over_rccl():
@@ -360,4 +559,5 @@ def test_bench_with_two_ranks_over_rccl():
     if _native.device_count() < 2:
         pytest.skip("needs two GPUs")
     d = _run_bench_ranks(2, [])
-    assert d["n_gpus"] == 2 and d["config"]["collective"] == "RCCL gather" and d["config"]["reference_queries_per_frame"] == 17874992
+    assert d["n_gpus"] == 2 and d["config"]["collective"] == "RCCL gather"
+    _check_frame_counts(d)

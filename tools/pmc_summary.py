@@ -41,6 +41,11 @@ if "--traffic-json" in sys.argv:
     except OSError:
         extra["commit"] = None
     extra["date"] = datetime.date.today().isoformat()
+    # which kernel sources the counters belong to: bench.py uses the numbers only while the tree still holds these
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import source_digest
+    extra["sources"] = source_digest()
     if fk is not None and wk is not None:
         json.dump({"kernel": "k_level", "workload": workload, "fetch_size_kib_per_launch": round(fk, 1),
                    "write_size_kib_per_launch": round(wk, 1), "fetch_correction": 2.0,
