@@ -351,6 +351,33 @@ def main():
     last = ctx.render_rows_device(options, 0, tile.row0, tile.nrows, alone.data_ptr(), stream=streams[0].cuda_stream,
                                   want_stats=True, row_stride=tile.stride)
     sync()
+    # the same frame as two bands of rows traced at once by two contexts (t3d_render_rows_device_split): what a caller
+    # with ONE frame to render gets; timed by events on the stream the bands are forked from and joined to
+    two_bands_ms = None
+    if not lbvh_scene and not args.no_secondary and tile.nrows >= 16:
+        pair = ctxs[:2] if F >= 2 else [ctx, _native.Context(local_rank)]
+        if F < 2:
+            pair[1].upload(flat)
+        for c in pair:
+            c.set_timing(False)
+            c.set_full_rounds(False)
+        banded = torch.empty_like(alone)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        times = []
+        for i in range(8 + 21):
+            e0.record(streams[0])
+            _native.render_rows_split(pair, options, 0, tile.row0, tile.nrows, bgr_ptr=banded.data_ptr(), stream=streams[0].cuda_stream,
+                                      row_stride=tile.stride)
+            e1.record(streams[0])
+            streams[0].synchronize()
+            if i >= 8:
+                times.append(e0.elapsed_time(e1))
+        _native.split_call_stats(pair)          # raises if a band overflowed its buffers
+        if not torch.equal(banded, alone):
+            raise RuntimeError("the frame traced as two bands differs from the frame traced alone")
+        two_bands_ms = sorted(times)[len(times) // 2]
+        ctx.set_timing(True)
+        sync()
     whole_alone_ms = None
     if world > 1 and not args.no_secondary:
         # the whole frame on ONE GPU (rank 0's), alone, while the other ranks wait: what the several-rank figures compare with
@@ -424,6 +451,8 @@ def main():
                                                             / level_s / 1e12 / FP32_VALU_PEAK_TFLOPS, 4) if level_s > 0 else None},
             # the whole pipeline as timed: every flop of a frame over the time a frame takes with F calls in flight
             "pipeline": {"frames_in_flight": F * B, "frame_latency_ms": round(last["ms_device"], 4),
+                         # one frame alone on the device again, its rows as two bands traced at once by two contexts
+                         "frame_latency_two_bands_ms": round(two_bands_ms, 4) if two_bands_ms else None,
                          # this rank's share of one frame with nothing else on the device, as a rate
                          "frame_alone_mrays": round(last_traced / (last["ms_device"] * 1e-3) / 1e6, 2) if last["ms_device"] > 0 else None,
                          "achieved": round(frame_flops / (ms_per_step * 1e-3) / 1e12, 3), "unit": "TFLOP/s",

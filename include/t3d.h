@@ -217,6 +217,23 @@ int t3d_render_rows_async(t3d_ctx* ctx, const t3d_opts* opts, int row0, int nrow
 int t3d_render_frame_multi(t3d_ctx* const* ctxs, int n, const t3d_opts* opts, uint8_t* bgr_frame, int frame_on_device,
                            t3d_stats* stats);
 
+/*
+ * The rows of one call as n contiguous bands of rows, band k traced by ctxs[k] -- contexts of ONE device that hold the
+ * same scene -- all bands at once, each on its context's own stream.  For the latency of a single frame: the launches
+ * of one band leave part of the device empty while they start and while their last waves finish, and another band's
+ * launches fill it (1920x1080, 4 bounces: 0.52 ms on one context, 0.44 ms as two bands; more bands gain nothing, and a
+ * caller that keeps several frames in flight on several contexts already has this overlap).  Towards the caller the call
+ * behaves like t3d_render_rows_device without `stats` on `stream` (NULL: the stream of ctxs[0]): the bands' streams
+ * are forked from it and joined to it by events, the pixels are those of one call, nothing is waited for;
+ * t3d_last_call_stats of every context gives the counters of its band (their sum is the call's), and reports a band
+ * whose trace trees did not fit its buffers, as after t3d_render_rows_device.  opts->frames must be 0 or 1.
+ * t3d_render_rows_async_split is t3d_render_rows_async in the same way: the finished rows are copied to `bgr_pinned` on
+ * the stream of ctxs[0].  Stands where Photon.render starts its stripe threads (T3DR.py:1111-1137).
+ */
+int t3d_render_rows_device_split(t3d_ctx* const* ctxs, int n, const t3d_opts* opts, int row0, int nrows,
+                                 uint8_t* bgr_device, void* stream);
+int t3d_render_rows_async_split(t3d_ctx* const* ctxs, int n, const t3d_opts* opts, int row0, int nrows, uint8_t* bgr_pinned);
+
 /* Page-locked host memory for t3d_render_rows_async outputs (thin wrappers; no counterpart in the reference). */
 int t3d_host_alloc(size_t bytes, void** out);
 int t3d_host_free(void* p);

@@ -18,7 +18,7 @@ SYMBOLS = ("t3d_abi_version", "t3d_device_count", "t3d_create", "t3d_destroy", "
            "t3d_upload_scene", "t3d_render_rows", "t3d_render_rows_device", "t3d_trace_pixel", "t3d_trace_ray",
            "t3d_closest_hits", "t3d_last_call_stats", "t3d_set_timing", "t3d_set_accel", "t3d_set_rounds", "t3d_set_cancel",
            "t3d_render_rows_async", "t3d_host_alloc", "t3d_host_free", "t3d_render_frame_multi",
-           "t3d_render_rows_device_static", "t3d_graph_counters",
+           "t3d_render_rows_device_static", "t3d_graph_counters", "t3d_render_rows_device_split", "t3d_render_rows_async_split",
            "t3d_post_upscale_device", "t3d_post_denoise_device", "t3d_post_upscale", "t3d_post_denoise")
 
 
@@ -122,6 +122,10 @@ def load():
     lib.t3d_host_alloc.argtypes = [C.c_size_t, P(C.c_void_p)]
     lib.t3d_host_free.restype = C.c_int
     lib.t3d_host_free.argtypes = [C.c_void_p]
+    lib.t3d_render_rows_device_split.restype = C.c_int
+    lib.t3d_render_rows_device_split.argtypes = [P(C.c_void_p), C.c_int, P(Opts), C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.t3d_render_rows_async_split.restype = C.c_int
+    lib.t3d_render_rows_async_split.argtypes = [P(C.c_void_p), C.c_int, P(Opts), C.c_int, C.c_int, C.c_void_p]
     lib.t3d_graph_counters.restype = C.c_int
     lib.t3d_graph_counters.argtypes = [C.c_void_p, P(C.c_uint64), P(C.c_uint64), P(C.c_uint64)]
     lib.t3d_set_cancel.restype = C.c_int
@@ -376,6 +380,52 @@ class Context:
         self._check(self._lib.t3d_closest_hits(self._h, n, _ptr(o), _ptr(d), int(lights), int(back_cull), _ptr(obj),
                                                _ptr(face), _ptr(t), _ptr(dirflag), _ptr(normal)), "t3d_closest_hits")
         return dict(obj=obj, face=face, t=t, direction=dirflag, normal=normal)
+
+
+def render_rows_split(contexts, options: dict, seed: int, row0: int, nrows: int, bgr_ptr: int = 0, stream: int = 0, out=None,
+                      row_stride: int = 1):
+    """The rows of one call as ``len(contexts)`` contiguous bands, band k traced by ``contexts[k]`` (contexts of one
+    device holding the same scene), all at once: shorter latency for a single frame.  Not waited for.  Output: the device
+    address ``bgr_ptr`` (``t3d_render_rows_device_split``, on ``stream``) or ``out``, a ``pinned_image`` of shape
+    [nrows, W, 3] (``t3d_render_rows_async_split``).  ``split_call_stats(contexts)`` waits and returns the counters."""
+    lib = load()
+    n = len(contexts)
+    opts = make_opts(options, seed, row_stride=row_stride)
+    handles = (C.c_void_p * n)(*[c._h for c in contexts])
+    if out is not None:
+        if out.dtype != np.uint8 or out.shape != (nrows, opts.width, 3) or not out.flags.c_contiguous:
+            raise ValueError(f"out must be a C-contiguous uint8 array of shape {(nrows, opts.width, 3)}")
+        rc = lib.t3d_render_rows_async_split(handles, n, C.byref(opts), row0, nrows, _ptr(out))
+        contexts[0]._check(rc, "t3d_render_rows_async_split")
+    else:
+        rc = lib.t3d_render_rows_device_split(handles, n, C.byref(opts), row0, nrows, C.c_void_p(bgr_ptr or None), C.c_void_p(stream or None))
+        contexts[0]._check(rc, "t3d_render_rows_device_split")
+
+
+def split_call_stats(contexts):
+    """Waits for a ``render_rows_split`` call and returns its counters: the sum over the bands (times: the slowest band's).
+    Raises ``NativeError`` (code E_CAPACITY) if a band's trace trees did not fit its buffers -- after every context has
+    been asked, so that none is left with an unreported overflow."""
+    total, error = None, None
+    for c in contexts:
+        try:
+            st = c.last_call_stats()
+        except NativeError as e:
+            error = error or e
+            continue
+        if total is None:
+            total = st
+        else:
+            for k, v in st.items():
+                if isinstance(v, list):
+                    total[k] = [max(a, b) if k == "level_ms" else a + b for a, b in zip(total[k], v)]
+                elif k.startswith("ms_"):
+                    total[k] = max(total[k], v)
+                else:
+                    total[k] += v
+    if error is not None:
+        raise error
+    return total
 
 
 def render_frame_multi(contexts, options: dict, seed: int, out=None, frame_ptr: int = 0):

@@ -126,7 +126,7 @@ struct DevScene {
     const DevShader* shaders;  // [K]
     const float* obj_ior;      // [O]
     const float4* prim_info;   // [3 (T + S)]: what the classification of a hit needs about its primitive, gathered in one go
-                               //   row 0: the triangle's un-normalised normal (sphere: its centre), w = ior of the primitive's object
+                               //   row 0: the triangle's unit normal (sphere: its centre), w = ior of the primitive's object
                                //   row 1: int bits: object, face in its mesh (sphere: -1), shader, kind (bit 0 emitter, bit 1 sphere)
                                //   row 2: roughness, reflectivity, emission strength (Light: its strength),
                                //          visibility a shadow ray is left with when this primitive is the first thing it hits
@@ -264,6 +264,17 @@ struct GroupCount;
 #define GC_ADD(gc, field, n) do { } while (0)
 #endif
 
+#ifdef T3D_WAVE_TRACE
+// instrumented build only: when every wave of a k_level launch started and ended (s_memrealtime, 100 MHz), how many
+// rounds it ran and where it ran (HW_ID register)
+#define T3D_WAVE_TRACE_MAX (1 << 16)
+__device__ unsigned long long g_wave_trace[T3D_MAX_BOUNCES + 1][T3D_WAVE_TRACE_MAX][4];
+extern "C" int t3d_debug_wave_trace(int level, unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_trace), sizeof(unsigned long long) * 4 * (size_t)n,
+                               sizeof(unsigned long long) * 4 * T3D_WAVE_TRACE_MAX * (size_t)level) == hipSuccess ? 0 : -1;
+}
+#endif
+
 struct Hit {
     float t;
     int prim;  // < 0 miss; [0, T) triangle (plane-group order); T + s sphere s
@@ -292,17 +303,31 @@ __device__ __forceinline__ f2 step01(f2 m, f2 big) {
 // The hit flags of a group (at most 24 triangles) are collected as the bits of an integer kept in a float:
 //     A = 2 A + step01(min3(u, v, w))
 // so its highest set bit is the FIRST triangle hit, which is the one the reference keeps (T3DR.py:715).
-template <int AX, bool NO_CULL>
+// The plane rows of a small scene (at most T3D_TAB_GROUPS groups) held in two registers per lane for the whole launch:
+// lane 2g of `a` holds n.x of group g, lane 2g + 1 its offset, `b` likewise n.y and n.z.  A row is then four v_readlane
+// away (a few issue cycles) instead of a scalar-memory request (some 200 cycles from the scalar cache).
+#define T3D_TAB_GROUPS 32
+struct PlaneTab {
+    int a, b;
+};
+template <int AX, bool NO_CULL, bool TAB = false>
 __device__ __forceinline__ void plane_groups(const float4* __restrict__ planes, const int* __restrict__ plane_first,
                                              const float4* __restrict__ tri_uv, int g_begin, int g_end, f2 ox, f2 oy, f2 oz,
                                              f2 dx, f2 dy, f2 dz, f2 cull, f2 big, uint32_t& best0, uint32_t& best1, float& A0,
-                                             float& A1, int& bg0, int& bg1, GroupCount* gc = nullptr) {
+                                             float& A1, int& bg0, int& bg1, GroupCount* gc = nullptr, PlaneTab tab = PlaneTab{0, 0}) {
     const f2 os = AX == 0 ? oy : (AX == 1 ? oz : ox), ot = AX == 0 ? oz : (AX == 1 ? ox : oy);
     const f2 ds = AX == 0 ? dy : (AX == 1 ? dz : dx), dt = AX == 0 ? dz : (AX == 1 ? dx : dy);
     for (int g = g_begin; g < g_end; ++g) {
         // One 96-byte record per group: plane row, triangle range, and the rows of its first two triangles --
         // requested together, so a group of up to two triangles costs a single wait on scalar memory.
-        const float4 rn = planes[6 * g], rk = planes[6 * g + 1];
+        float4 rn;
+        if constexpr (TAB) {
+            rn.x = __int_as_float(__builtin_amdgcn_readlane(tab.a, 2 * g)); rn.y = __int_as_float(__builtin_amdgcn_readlane(tab.a, 2 * g + 1));
+            rn.z = __int_as_float(__builtin_amdgcn_readlane(tab.b, 2 * g)); rn.w = __int_as_float(__builtin_amdgcn_readlane(tab.b, 2 * g + 1));
+        } else {
+            rn = planes[6 * g];
+        }
+        const float4 rk = planes[6 * g + 1];
         const float4 fa0 = planes[6 * g + 2], fb0 = planes[6 * g + 3], fa1 = planes[6 * g + 4], fb1 = planes[6 * g + 5];
         const f2 dn = fma2(splat(rn.w), dz, fma2(splat(rn.z), dy, splat(rn.x) * dx));
         const f2 q = fma2(splat(rn.w), oz, fma2(splat(rn.z), oy, fma2(splat(rn.x), ox, splat(rn.y))));  // n.o - n.v0
@@ -318,7 +343,7 @@ __device__ __forceinline__ void plane_groups(const float4* __restrict__ planes, 
         const uint32_t tp0 = __float_as_uint(t.x), tp1 = __float_as_uint(t.y);
         // four of five groups are entered: their range and first rows are asked for together with the plane row (this empty
         // statement needs them, so the requests stay in front of the branch)
-        asm volatile("" :: "s"(rk.w), "s"(fa0.w), "s"(fb0.w));
+        if constexpr (!TAB) asm volatile("" :: "s"(rk.w), "s"(fa0.w), "s"(fb0.w));
         GC_ADD(gc, visited, 1);
         if (!__any((tp0 < best0) | (tp1 < best1))) continue;  // wave-uniform
         GC_ADD(gc, entered, 1);
@@ -385,10 +410,10 @@ __device__ __forceinline__ bool ray_meets_scene_box(const DevGeo& geo, V3 o, V3 
     return tn <= tf;
 }
 
-template <bool BOX_FIRST = false, bool NO_CULL = false>
+template <bool BOX_FIRST = false, bool NO_CULL = false, bool TAB = false>
 __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0, V3 d0, V3 o1, V3 d1,
                                              bool lights, bool back_cull0, bool back_cull1, Hit& out0, Hit& out1, GroupCount* gc = nullptr,
-                                             float bound0 = __builtin_inff(), float bound1 = __builtin_inff()) {
+                                             float bound0 = __builtin_inff(), float bound1 = __builtin_inff(), PlaneTab tab = PlaneTab{0, 0}) {
     // bound0 / bound1: only hits nearer than this count (non-negative; +inf: no bound).  The closest hit below the bound is
     // the closest hit, and a plane group that no ray of the wave meets below its bound is skipped like one that no ray
     // meets below its best distance.
@@ -405,9 +430,9 @@ __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0
     int bg0 = 0, bg1 = 0;
     int prim0 = -1, prim1 = -1, back0 = 0, back1 = 0;
     if (any_inside) {
-    plane_groups<0, NO_CULL>(planes, plane_first, tri_uv, 0, geo.axis_end[0], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1, gc);
-    plane_groups<1, NO_CULL>(planes, plane_first, tri_uv, geo.axis_end[0], geo.axis_end[1], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1, gc);
-    plane_groups<2, NO_CULL>(planes, plane_first, tri_uv, geo.axis_end[1], geo.axis_end[2], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1, gc);
+    plane_groups<0, NO_CULL, TAB>(planes, plane_first, tri_uv, 0, geo.axis_end[0], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1, gc, tab);
+    plane_groups<1, NO_CULL, TAB>(planes, plane_first, tri_uv, geo.axis_end[0], geo.axis_end[1], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1, gc, tab);
+    plane_groups<2, NO_CULL, TAB>(planes, plane_first, tri_uv, geo.axis_end[1], geo.axis_end[2], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1, gc, tab);
     if (A0 >= 1.0f) prim0 = first_hit_of_group(plane_first, bg0, A0);   // some group was hit (its hit bits are kept with it)
     if (A1 >= 1.0f) prim1 = first_hit_of_group(plane_first, bg1, A1);
     // Spheres and lights.  getSphereCollision (T3DR.py:572-598), Ray.getTSphere (T3DE.py:145-163).
@@ -674,16 +699,16 @@ __device__ __forceinline__ void camera_ray(const DevCamera& cam, const RenderPar
 // Direct-light term of a (node, light) pair given the closest hit of its shadow ray: getDirectLight for
 // one light (T3DR.py:839-894) with getVisibility (T3DR.py:762-778).
 struct ShadowRay {
-    V3 P, N, Ld, start;
+    V3 P, N, to, Ld, start;   // to = light - P (not normalised), Ld = its direction
     float rough, dist2, strength;
     float reach;   // a little more than the distance from the ray's start to the light's position
 };
 __device__ __forceinline__ ShadowRay shadow_ray(const DevLight lt, float4 ra, float4 rb) {
     ShadowRay s;
     s.P = mk(ra.x, ra.y, ra.z); s.N = mk(rb.x, rb.y, rb.z); s.rough = ra.w;
-    const V3 to = mk(lt.x - s.P.x, lt.y - s.P.y, lt.z - s.P.z);
-    s.dist2 = dot(to, to);
-    s.Ld = to * __builtin_amdgcn_rsqf(s.dist2);
+    s.to = mk(lt.x - s.P.x, lt.y - s.P.y, lt.z - s.P.z);
+    s.dist2 = dot(s.to, s.to);
+    s.Ld = s.to * __builtin_amdgcn_rsqf(s.dist2);
     s.start = madd(s.P, s.Ld, 0.2f);  // T3DR.py:840
     s.strength = lt.strength;
     s.reach = fmaf(fmaxf(s.dist2 * __builtin_amdgcn_rsqf(s.dist2) - 0.2f, 0.0f), 1.0001f, 1e-3f);
@@ -693,15 +718,44 @@ __device__ __forceinline__ ShadowRay shadow_ray(const DevScene& sc, float4 ra, f
 // The part of the light term that does not depend on what the shadow ray hits: diffuse and specular response of the
 // surface to the light's direction (T3DR.py:850-857, 880).  Where it is zero -- the surface faces away from the light
 // and shows no highlight to the camera -- the term is zero whatever the visibility, and the ray need not be traced.
-__device__ __forceinline__ float shadow_facing(const DevScene& sc, const ShadowRay& s) {
-    const V3 cam = mk(sc.cam.pos[0], sc.cam.pos[1], sc.cam.pos[2]);
-    const float ldn = dot(s.Ld, s.N);
-    const float diffuse = fmaxf(0.0f, ldn);
-    const V3 R = madd(s.Ld * -1.0f, s.N, 2.0f * ldn);
-    const float spec = (dot(normalize(R), normalize(cam - s.P)) < 0.96f) ? 0.0f : 1.0f;
-    return diffuse * s.rough + spec * (1.0f - s.rough);
+// Worked out from the un-normalised vector to the light, `to`, and the un-normalised vector to the camera, V, so that the
+// test at node creation (which asks only whether the response is zero) needs no square root at all:
+//   diffuse   max(0, L^.N) = to.N / |to| where to.N > 0, else exactly 0
+//   specular  R^.V^ >= 0.96 with R = 2 (L^.N) N - L^ (unit, like L^ and N):  R' = 2 (to.N) N - to = |to| R, so the test is
+//             R'.V >= 0.96 |to| |V|, i.e. R'.V > 0 and (R'.V)^2 >= 0.9216 |to|^2 |V|^2
+// Both users call the same code, so a pair is culled exactly when its intensity would be multiplied by an exact zero.
+struct LightResponse {
+    float tn;     // to . N
+    bool spec;    // the camera sees the light's mirror image at the point (T3DR.py:857)
+};
+__device__ __forceinline__ LightResponse light_response(V3 to, float dist2, V3 N, V3 V, float vv) {
+    LightResponse r;
+    r.tn = dot(to, N);
+    const float two_tn = r.tn + r.tn;
+    const float rv = fmaf(fmaf(N.z, two_tn, -to.z), V.z, fmaf(fmaf(N.y, two_tn, -to.y), V.y, fmaf(N.x, two_tn, -to.x) * V.x));
+    r.spec = rv > 0.0f && rv * rv >= 0.9216f * dist2 * vv;
+    return r;
 }
-__device__ __forceinline__ bool shadow_dead(const DevScene& sc, const ShadowRay& s) { return shadow_facing(sc, s) == 0.0f || s.strength == 0.0f; }
+// is the response zero?  (no division, no square root)
+__device__ __forceinline__ bool response_zero(const LightResponse& r, float rough, float strength) {
+    const bool diffuse = r.tn > 0.0f && rough != 0.0f, mirror = r.spec && rough != 1.0f;
+    return !(diffuse || mirror) || strength == 0.0f;
+}
+__device__ __forceinline__ bool light_dead(const DevLight lt, V3 P, V3 N, V3 V, float vv, float rough) {
+    const V3 to = mk(lt.x - P.x, lt.y - P.y, lt.z - P.z);   // as shadow_ray forms it
+    return response_zero(light_response(to, dot(to, to), N, V, vv), rough, lt.strength);
+}
+__device__ __forceinline__ float shadow_facing(const DevScene& sc, const ShadowRay& s) {
+    const V3 V = mk(sc.cam.pos[0] - s.P.x, sc.cam.pos[1] - s.P.y, sc.cam.pos[2] - s.P.z);
+    const LightResponse r = light_response(s.to, s.dist2, s.N, V, dot(V, V));
+    const float diffuse = r.tn > 0.0f && s.rough != 0.0f ? r.tn * __builtin_amdgcn_rsqf(s.dist2) * s.rough : 0.0f;
+    const float mirror = r.spec && s.rough != 1.0f ? 1.0f - s.rough : 0.0f;
+    return diffuse + mirror;
+}
+__device__ __forceinline__ bool shadow_dead(const DevScene& sc, const ShadowRay& s) {
+    const V3 V = mk(sc.cam.pos[0] - s.P.x, sc.cam.pos[1] - s.P.y, sc.cam.pos[2] - s.P.z);
+    return response_zero(light_response(s.to, s.dist2, s.N, V, dot(V, V)), s.rough, s.strength);
+}
 __device__ __forceinline__ float shadow_intensity(const DevScene& sc, const DevSphere* __restrict__ spheres, const ShadowRay& s,
                                                   const Hit& h) {
     // getVisibility (T3DR.py:762-778): 1 - reflectivity of the first thing hit unless that is a light or an emissive face
@@ -794,9 +848,12 @@ __device__ __forceinline__ Outcome hit_outcome(const DevScene& sc, const RenderP
         const int kind = __float_as_int(i1.w);
         r.obj = __float_as_int(i1.x); r.face = __float_as_int(i1.y); r.shader = __float_as_int(i1.z);
         if (!(kind & 2)) {
-            r.Nraw = mk(i0.x, i0.y, i0.z);
-            r.N = normalize(r.Nraw);
-            r.dirflag = (dot(r.Nraw, d) < 0.0f) ? 0 : 1;
+            // the record holds the unit normal (normalised in float64 at upload); the normal as the reference stores it,
+            // un-normalised, only goes into debug records
+            r.N = mk(i0.x, i0.y, i0.z);
+            r.Nraw = r.N;
+            if (ONE && rp.want_debug) { const float4 rn = sc.tri_n[h.prim]; r.Nraw = mk(rn.x, rn.y, rn.z); }
+            r.dirflag = (dot(r.N, d) < 0.0f) ? 0 : 1;
         } else {
             r.dirflag = h.back;
             r.N = normalize(mk(r.P.x - i0.x, r.P.y - i0.y, r.P.z - i0.z));
@@ -964,12 +1021,13 @@ __device__ __forceinline__ void process_rays(const DevScene& sc, const DevLight*
     for (int r = 0; r < NR; ++r) {
         live[r] = 0; pair_pos[r] = 0;
         if constexpr (RING > 0 && PAIRS) {
-            const float4 ra = make_float4(oc[r].P.x, oc[r].P.y, oc[r].P.z, oc[r].rough), rb = make_float4(oc[r].N.x, oc[r].N.y, oc[r].N.z, 0.0f);
+            const V3 V = mk(sc.cam.pos[0] - oc[r].P.x, sc.cam.pos[1] - oc[r].P.y, sc.cam.pos[2] - oc[r].P.z);
+            const float vv = dot(V, V);
             pair_pos[r] = pairs_total;
             for (int l = 0; l < wc.L; ++l) {
                 // lights: the light array as a kernel argument of its own, so that this wave-uniform read goes through the
                 // scalar cache (through the pointer in the scene structure it would be a vector load, waited for per light)
-                const bool lv = oc[r].shaded && !shadow_dead(sc, shadow_ray(lights[l], ra, rb));
+                const bool lv = oc[r].shaded && !light_dead(lights[l], oc[r].P, oc[r].N, V, vv, oc[r].rough);
                 const unsigned long long m = __ballot(lv);
                 pair_pos[r] += __popcll(m & wc.lt_mask);
                 pairs_total += __popcll(m);
@@ -1161,6 +1219,18 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_level(DevScene sc, GEO_PARAMS
     int items_done = 0;  // (node, light) pairs already traced     (wave-uniform)
     const float inv_L = 1.0f / (float)(L > 0 ? L : 1);
     PairList pl{PAIRS ? pair_ring_all[wc.wid] : nullptr, 0, 0u};
+#ifdef T3D_EXP_TAB
+    constexpr bool TAB = true;
+    const int* tab_src = (const int*)(planes + 6 * (sc.n_planes + 1));
+    const PlaneTab tab{tab_src[wc.lane], tab_src[64 + wc.lane]};
+#else
+    constexpr bool TAB = false;
+    const PlaneTab tab{0, 0};
+#endif
+#ifdef T3D_WAVE_TRACE
+    const unsigned long long wt_start = __builtin_amdgcn_s_memrealtime();
+    unsigned wt_trace = 0, wt_shadow = 0;
+#endif
 #ifdef T3D_COUNT_GROUPS
     GroupCount gct{0, 0, 0, 0}, gcs{0, 0, 0, 0};
     GroupCount *gcp_t = &gct, *gcp_s = &gcs;
@@ -1200,10 +1270,10 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_level(DevScene sc, GEO_PARAMS
             // has no distance check (T3DR.py:762-778): a ray that finds nothing up to there (a Light of radius zero, a
             // start inside the Light) goes on through the whole scene.
             Hit h0, h1;
-            closest_hit2<false, true>(GEO_ARGS, sc.geo, s0.start, s0.Ld, s1.start, s1.Ld, true, false, false, h0, h1, gcp_s, s0.reach, s1.reach);
+            closest_hit2<false, true, TAB>(GEO_ARGS, sc.geo, s0.start, s0.Ld, s1.start, s1.Ld, true, false, false, h0, h1, gcp_s, s0.reach, s1.reach, tab);
             if (__any((int)(h0.prim < 0) | (int)(h1.prim < 0))) {   // wave-uniform
                 Hit g0, g1;
-                closest_hit2<false, true>(GEO_ARGS, sc.geo, s0.start, s0.Ld, s1.start, s1.Ld, true, false, false, g0, g1, gcp_s);
+                closest_hit2<false, true, TAB>(GEO_ARGS, sc.geo, s0.start, s0.Ld, s1.start, s1.Ld, true, false, false, g0, g1, gcp_s, __builtin_inff(), __builtin_inff(), tab);
                 if (h0.prim < 0) h0 = g0;
                 if (h1.prim < 0) h1 = g1;
             }
@@ -1211,14 +1281,21 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_level(DevScene sc, GEO_PARAMS
             if (run0) pool.li[(wc.node_base + (size_t)__float_as_int(rb0.w)) * L + l0] = I0;
             if (run1) pool.li[(wc.node_base + (size_t)__float_as_int(rb1.w)) * L + l1] = I1;
             items_done += pending < 128 ? pending : 128;
+#ifdef T3D_WAVE_TRACE
+            ++wt_shadow;
+#endif
         } else if (more) {
+#ifdef T3D_WAVE_TRACE
+            ++wt_trace;
+#endif
             // ---------------- trace round: rays chunk*cs + lane and (cs = 128) chunk*cs + 64 + lane ----------------
             RayIn in[2];
             load_ray<LEVEL0, ONE>(sc, rp, rays_in, chunk * cs + wc.lane, wc.lane < cs ? n_in : 0, queue_base, in[0]);
             load_ray<LEVEL0, ONE>(sc, rp, rays_in, chunk * cs + 64 + wc.lane, cs == 128 ? n_in : 0, queue_base, in[1]);
             const bool lights = LEVEL0 ? (rp.lights != 0) : true;
             Hit h[2];  // back faces culled iff ray.ior == 1 (T3DR.py:961)
-            closest_hit2<LEVEL0>(GEO_ARGS, sc.geo, in[0].o, in[0].d, in[1].o, in[1].d, lights, in[0].ior == 1.0f, in[1].ior == 1.0f, h[0], h[1], gcp_t);
+            closest_hit2<LEVEL0, false, TAB>(GEO_ARGS, sc.geo, in[0].o, in[0].d, in[1].o, in[1].d, lights, in[0].ior == 1.0f, in[1].ior == 1.0f, h[0], h[1], gcp_t,
+                                             __builtin_inff(), __builtin_inff(), tab);
             process_rays<LEVEL0, RING, PAIRS, ONE, 2>(sc, light_rows, rp, wc, in, h, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes, &pl);
             chunk += chunk_step;
             // the ring is private to this wave; LDS operations of one wave complete in order, the fences
@@ -1230,6 +1307,18 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_level(DevScene sc, GEO_PARAMS
             break;
         }
     }
+#ifdef T3D_WAVE_TRACE
+    if (wc.lane == 0 && gw < T3D_WAVE_TRACE_MAX) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_wave_trace[level][gw][0] = wt_start;
+        g_wave_trace[level][gw][1] = __builtin_amdgcn_s_memrealtime();
+        g_wave_trace[level][gw][2] = (unsigned long long)wt_trace | ((unsigned long long)wt_shadow << 32);
+        g_wave_trace[level][gw][3] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+    }
+#endif
 #ifdef T3D_COUNT_GROUPS
     if (wc.lane == 0) {
         atomicAdd(&g_group_count[0], (unsigned long long)gct.calls); atomicAdd(&g_group_count[1], (unsigned long long)gct.visited);
@@ -1682,6 +1771,7 @@ struct t3d_ctx {
     bool call_totals = false;         // d_totals holds the counters of the most recent call
     uint64_t call_n0 = 0;             // its primary samples
     hipEvent_t ev_call0 = nullptr;    // start of its first band (recorded when events are)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // t3d_render_rows_device_split: the caller's stream -> this context's, and back
 };
 
 static thread_local std::string g_create_err;
@@ -1739,6 +1829,8 @@ extern "C" int t3d_create(int device, t3d_ctx** out) {
         hipHostMalloc((void**)&c->h_totals, sizeof(CallTotals), hipHostMallocDefault) != hipSuccess)
         return fail(T3D_E_NOMEM, "counter allocation failed");
     if ((e = hipEventCreate(&c->ev_call0)) != hipSuccess) return fail(T3D_E_DEVICE, hipGetErrorString(e));
+    if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail(T3D_E_DEVICE, hipGetErrorString(e));
+    if ((e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) return fail(T3D_E_DEVICE, hipGetErrorString(e));
     c->h_sticky[0] = c->h_sticky[1] = 0;
     c->static_scratch = static_scratch_for(device, &e);   // the device is current
     if (!c->static_scratch) return fail(T3D_E_DEVICE, std::string("address of the static work array: ") + hipGetErrorString(e));
@@ -1782,6 +1874,8 @@ extern "C" void t3d_destroy(t3d_ctx* c) {
     hipFree(c->d_totals);
     if (c->h_totals) hipHostFree(c->h_totals);
     if (c->ev_call0) hipEventDestroy(c->ev_call0);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
     for (auto& g : c->graphs) if (g.valid) { hipGraphExecDestroy(g.exec); hipGraphDestroy(g.graph); }
     hipFree(c->d_bgr); hipFree(c->d_rad); hipFree(c->d_prim); hipFree(c->d_prim_t);
     if (c->h_stage) hipHostFree(c->h_stage);
@@ -1914,7 +2008,7 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
         }
     }
     const size_t G = pieces.size();
-    std::vector<float4> planes(6 * (G + 1), make_float4(0.f, 0.f, 0.f, 0.f));
+    std::vector<float4> planes(6 * (G + 1) + T3D_TAB_GROUPS, make_float4(0.f, 0.f, 0.f, 0.f));   // group records, then the plane rows as a register table
     std::vector<int> plane_first(G + 1, 0);
     std::vector<float4> tri_uv((size_t)2 * (s->n_tris + 1), make_float4(0.f, 0.f, 0.f, 0.f));
     std::vector<float4> tri_n((size_t)s->n_tris + 1, make_float4(0.f, 0.f, 0.f, 0.f));
@@ -1952,6 +2046,13 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
             }
         }
         plane_first[G] = k;
+        {   // PlaneTab: (n.x, offset) of group g at floats 2g, 2g + 1; (n.y, n.z) at 64 + 2g, 64 + 2g + 1
+            float* tabf = (float*)&planes[6 * (G + 1)];
+            for (size_t g = 0; g < G && g < T3D_TAB_GROUPS; ++g) {
+                tabf[2 * g] = planes[6 * g].x; tabf[2 * g + 1] = planes[6 * g].y;
+                tabf[64 + 2 * g] = planes[6 * g].z; tabf[64 + 2 * g + 1] = planes[6 * g].w;
+            }
+        }
         if (want_bvh) {
             for (int t = 0; t < s->n_tris; ++t) {
                 const Tri& T = tris[t];
@@ -2014,7 +2115,12 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
             const int4 m = meta[k];
             const DevShader& sh = shaders[m.z];
             const bool emitter = sh.emis > 0.0f;
-            prim_info[3 * (size_t)k + 0] = make_float4(tri_n[k].x, tri_n[k].y, tri_n[k].z, obj_ior[m.x]);
+            {   // unit normal, normalised in float64 (a degenerate triangle is never hit: any finite value will do)
+                const Tri& T = tris[order[k]];
+                const double len = sqrt(T.n[0] * T.n[0] + T.n[1] * T.n[1] + T.n[2] * T.n[2]);
+                const double inv = len > 0 ? 1.0 / len : 0.0;
+                prim_info[3 * (size_t)k + 0] = make_float4((float)(T.n[0] * inv), (float)(T.n[1] * inv), (float)(T.n[2] * inv), obj_ior[m.x]);
+            }
             prim_info[3 * (size_t)k + 1] = make_float4(ib(m.x), ib(m.y), ib(m.z), ib(emitter ? 1 : 0));
             prim_info[3 * (size_t)k + 2] = make_float4(sh.rough, sh.refl, sh.emis, emitter ? 1.0f : 1.0f - sh.refl);
         }
@@ -2918,6 +3024,66 @@ extern "C" int t3d_render_rows_async(t3d_ctx* c, const t3d_opts* o, int row0, in
     const size_t npix = (size_t)nrows * (o->frames > 1 ? o->frames : 1) * o->width;
     if ((rc = ensure_outputs(c, npix)) != T3D_OK) return rc;
     rc = t3d_render_rows_device(c, o, row0, nrows, c->d_bgr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(bgr_pinned, c->d_bgr, npix * 3, hipMemcpyDeviceToHost, c->stream));
+    return T3D_OK;
+}
+
+// The rows of one call as n contiguous bands, band k traced by context k on that context's own stream, all of them at
+// once: the launches of one band leave the device part empty while they start and while their last waves finish, and
+// another band's launches fill it (one 1080p frame: 0.52 ms on one context, 0.44 ms as two bands).  The contexts' streams
+// are forked from the call's stream and joined to it again by events, so to the caller the call behaves like
+// t3d_render_rows_device without stats on `st`.
+static int render_rows_split(t3d_ctx* const* ctxs, int n, const t3d_opts* o, int row0, int nrows, uint8_t* bgr_device, hipStream_t st) {
+    t3d_ctx* c0 = ctxs[0];
+    for (int k = 0; k < n; ++k) {
+        if (!ctxs[k]) { c0->err = "t3d_render_rows_device_split: null context"; return T3D_E_INVALID; }
+        if (ctxs[k]->device != c0->device) { c0->err = "t3d_render_rows_device_split: the contexts must share a device"; return T3D_E_INVALID; }
+        for (int j = 0; j < k; ++j) if (ctxs[j] == ctxs[k]) { c0->err = "t3d_render_rows_device_split: the same context twice"; return T3D_E_INVALID; }
+    }
+    if (o && o->frames > 1) { c0->err = "t3d_render_rows_device_split: one frame per call"; return T3D_E_INVALID; }
+    int rc = check_opts(c0, o, row0, nrows);
+    if (rc) return rc;
+    if (!bgr_device) { c0->err = "bgr output is required"; return T3D_E_INVALID; }
+    HIPCHK(c0, hipSetDevice(c0->device));
+    const int stride = o->row_stride > 1 ? o->row_stride : 1;
+    // bands of whole 8-row blocks (the unit of the pixel tiles level 0 walks) while there are enough rows for that
+    const int unit = nrows >= 8 * n ? 8 : 1;
+    auto bound = [&](int k) { return k >= n ? nrows : (int)((long long)nrows * k / n / unit * unit); };
+    if (n > 1) HIPCHK(c0, hipEventRecord(c0->ev_fork, st));
+    int first_error = T3D_OK;
+    for (int k = 0; k < n; ++k) {
+        t3d_ctx* c = ctxs[k];
+        const int b0 = bound(k), b1 = bound(k + 1);
+        if (b1 <= b0) continue;
+        hipStream_t sk = k == 0 ? st : c->stream;
+        if (k > 0) HIPCHK(c0, hipStreamWaitEvent(sk, c0->ev_fork, 0));
+        rc = t3d_render_rows_device(c, o, row0 + b0 * stride, b1 - b0, bgr_device + (size_t)b0 * o->width * 3, nullptr, nullptr, nullptr, sk, nullptr);
+        if (rc != T3D_OK && first_error == T3D_OK) { first_error = rc; if (k) c0->err = "band " + std::to_string(k) + ": " + c->err; }
+        if (k > 0) {
+            HIPCHK(c0, hipEventRecord(c->ev_join, sk));
+            HIPCHK(c0, hipStreamWaitEvent(st, c->ev_join, 0));
+        }
+    }
+    return first_error;
+}
+
+extern "C" int t3d_render_rows_device_split(t3d_ctx* const* ctxs, int n, const t3d_opts* o, int row0, int nrows, uint8_t* bgr_device, void* stream) {
+    if (!ctxs || n < 1 || n > 16 || !ctxs[0]) return T3D_E_INVALID;
+    return render_rows_split(ctxs, n, o, row0, nrows, bgr_device, stream ? (hipStream_t)stream : ctxs[0]->stream);
+}
+
+extern "C" int t3d_render_rows_async_split(t3d_ctx* const* ctxs, int n, const t3d_opts* o, int row0, int nrows, uint8_t* bgr_pinned) {
+    if (!ctxs || n < 1 || n > 16 || !ctxs[0]) return T3D_E_INVALID;
+    t3d_ctx* c = ctxs[0];
+    int rc = check_opts(c, o, row0, nrows);
+    if (rc) return rc;
+    if (!bgr_pinned) { c->err = "bgr output is required"; return T3D_E_INVALID; }
+    if (o->frames > 1) { c->err = "t3d_render_rows_async_split: one frame per call"; return T3D_E_INVALID; }
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t npix = (size_t)nrows * o->width;
+    if ((rc = ensure_outputs(c, npix)) != T3D_OK) return rc;
+    rc = render_rows_split(ctxs, n, o, row0, nrows, c->d_bgr, c->stream);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(bgr_pinned, c->d_bgr, npix * 3, hipMemcpyDeviceToHost, c->stream));
     return T3D_OK;

@@ -16,7 +16,9 @@ Differences a caller can observe, all deliberate:
   children below it that ``computeColor`` never looks at, T3DR.py:973, 1014-1041): same pixels and ``rays``, smaller
   trees from ``trace`` / ``traces``.
 * extra option keys: ``device`` (HIP device index, default 0), ``seed``, ``gpus`` (render the frame on that many
-  devices at once, rows interleaved; must divide ``height``) and ``devices`` (which ones).
+  devices at once, rows interleaved; must divide ``height``), ``devices`` (which ones) and ``bands`` (a frame rendered
+  without callbacks is traced as that many bands of rows at once on the one device, which shortens its latency; default:
+  two for small scenes and large frames, else one).
 """
 from __future__ import annotations
 
@@ -159,6 +161,7 @@ class Photon:
         self.uploads = 0           # scene uploads so far (a re-flattening with an unchanged digest is not one)
         self._multi = []           # [context, digest of its scene] per GPU when options['gpus'] > 1
         self._multi_devices = None
+        self._helpers = []         # [context, digest of its scene]: trace the other bands of a frame (options['bands'])
         self.scene = scene
         self.options = self.mergeDefaultOptions({} if options is None else options)
         self.rays = 0
@@ -231,6 +234,31 @@ class Photon:
             self._uploaded_digest = self._flat.digest()
             self.uploads += 1
         return self._context()
+
+    def _bands(self):
+        """How many bands of rows a plain render() traces at once: the launches of one 1080p frame of a small scene leave
+        part of the device empty at their starts and ends, which a second band's launches fill."""
+        o = self.options
+        if o.get("bands"):
+            return max(1, int(o["bands"]))
+        flat = self._flat
+        small_scene = flat is not None and flat.n_tris + flat.n_spheres <= 256
+        samples = int(o["samples"]) if int(o["bounces"]) > 1 else 1
+        return 2 if small_scene and int(o["width"]) * int(o["height"]) * samples >= 500_000 and int(o["height"]) >= 16 else 1
+
+    def _band_contexts(self):
+        """The contexts of a banded render, every one holding the scene of ``self._ctx``; just that one when the helpers
+        cannot be used."""
+        want = self._bands() - 1
+        if want <= 0 or self._flat is None or self._uploaded_digest is None:
+            return [self._ctx]
+        while len(self._helpers) < want:
+            self._helpers.append([_native.Context(int(self.options.get("device", 0))), None])
+        for slot in self._helpers[:want]:
+            if slot[1] != self._uploaded_digest:
+                slot[0].upload(self._flat)
+                slot[1] = self._uploaded_digest
+        return [self._ctx] + [slot[0] for slot in self._helpers[:want]]
 
     def _native_options(self):
         o = self.options
@@ -486,16 +514,25 @@ class Photon:
         early = None
         if plain and self._ctx is not None and self._uploaded_digest is not None:
             try:
-                self._ctx.render_rows_async(native_opts, seed, 0, height, image)
-                early = True
+                early = self._band_contexts()
+                if len(early) > 1:
+                    _native.render_rows_split(early, native_opts, seed, 0, height, out=image)
+                else:
+                    self._ctx.render_rows_async(native_opts, seed, 0, height, image)
             except _native.NativeError:
-                early = None     # e.g. an overflow left by an earlier call: the checked path below deals with it
+                # e.g. an overflow left by an earlier call: the checked path below deals with it; a helper may still hold one
+                for c in (early or [])[1:]:
+                    try:
+                        c.last_call_stats()
+                    except _native.NativeError:
+                        pass
+                early = None
         uploads_before = self.uploads
         ctx = self._prepare(force_flatten=True)
         self._baked = True  # transformedScene is rebuilt lazily from the current scene
         if early and self.uploads == uploads_before:      # the scene the device started on is still the scene
             try:
-                totals = ctx.last_call_stats()        # waits for the frame started above
+                totals = _native.split_call_stats(early)   # waits for the frame started above
             except _native.NativeError as e:
                 if e.code != _native.E_CAPACITY:
                     raise
@@ -505,7 +542,7 @@ class Photon:
                 # the frame started on the old device scene is thrown away -- and with it whatever it has to report: an
                 # overflow of its node buffers must not be handed to the checked call below as if it were its own
                 try:
-                    ctx.last_call_stats()
+                    _native.split_call_stats(early)
                 except _native.NativeError as e:
                     if e.code != _native.E_CAPACITY:
                         raise

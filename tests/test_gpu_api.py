@@ -293,6 +293,93 @@ def test_photon_render_on_several_gpus():
     assert multi.uploads == 4
 
 
+@pytest.mark.parametrize("accel", ["brute", "lbvh"])
+def test_rows_as_bands_traced_at_once(accel):
+    """t3d_render_rows_device_split / t3d_render_rows_async_split: the rows of a call as contiguous bands on several
+    contexts of the device at once -- the same pixels and, summed over the contexts, the same counters as one call."""
+    import torch
+    from raytracing_amd import _native
+    flat = flat_for("config2_cornell_light.json")
+    opt = dict(width=96, height=54, bounces=3, samples=2)
+    ctxs = [_native.Context(0) for _ in range(3)]
+    try:
+        for c in ctxs:
+            c.set_accel(accel)
+            c.upload(flat)
+        want = ctxs[0].render_rows(opt, seed=2)
+        keys = ("queries", "rays_api", "nodes", "shadow_queries", "trace_queries", "shadow_culled")
+        stream = torch.cuda.Stream()
+        for n in (1, 2, 3):
+            out = torch.zeros((54, 96, 3), dtype=torch.uint8, device="cuda:0")
+            for attempt in range(4):                       # an unchecked call may first have to learn the capacity it needs
+                _native.render_rows_split(ctxs[:n], opt, 2, 0, 54, bgr_ptr=out.data_ptr(), stream=stream.cuda_stream)
+                try:
+                    st = _native.split_call_stats(ctxs[:n])
+                    break
+                except _native.NativeError as e:
+                    assert e.code == _native.E_CAPACITY
+            stream.synchronize()
+            assert np.array_equal(out.cpu().numpy(), want["bgr"]), n
+            for k in keys:
+                assert st[k] == want["stats"][k], (k, n)
+        # a block of rows with a stride, into pinned host memory; fewer rows than eight per band
+        part = ctxs[0].render_rows(opt, seed=2, row0=3, nrows=10, row_stride=4)
+        img = _native.pinned_image((10, 96, 3))
+        _native.render_rows_split(ctxs, opt, 2, 3, 10, out=img, row_stride=4)
+        st = _native.split_call_stats(ctxs)
+        assert np.array_equal(img, part["bgr"]) and st["queries"] == part["stats"]["queries"]
+        with pytest.raises(_native.NativeError):             # one frame per call
+            lib_opts = dict(opt)
+            from raytracing_amd.flatten import make_opts
+            import ctypes as C
+            o = make_opts(lib_opts, 2, frames=2)
+            handles = (C.c_void_p * 2)(ctxs[0]._h, ctxs[1]._h)
+            ctxs[0]._check(_native.load().t3d_render_rows_device_split(handles, 2, C.byref(o), 0, 54, C.c_void_p(out.data_ptr()), None), "split")
+        with pytest.raises(_native.NativeError):             # the same context twice
+            _native.render_rows_split([ctxs[0], ctxs[0]], opt, 2, 0, 54, bgr_ptr=out.data_ptr())
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_photon_render_in_bands():
+    """options['bands']: a plain render() of an uploaded scene is traced as bands at once; same image, rays and stats."""
+    import T3DE
+    import T3DR
+    scene = T3DE.Scene.fromJSON(scene_path("cornellScene.json"))
+    opts = {"width": 96, "height": 72, "bounces": 3, "samples": 2, "seed": 4}
+    one = T3DR.Photon(scene, dict(opts, bands=1))
+    a0, a1 = one.render(), one.render()
+    for bands in (2, 3):
+        many = T3DR.Photon(scene, dict(opts, bands=bands))
+        b0 = many.render()                                     # first call: checked, one context
+        b1 = many.render()                                     # unchecked, in bands
+        b2 = many.render()
+        for b in (b0, b1, b2):
+            assert np.array_equal(b.imageAs("np"), a0.imageAs("np")) and b.rays == a0.rays
+        assert b2.stats["queries"] == a1.stats["queries"] and many.uploads == 1 and len(many._helpers) == bands - 1
+        ball = next(o for o in scene.objects if o.type == "sphere")
+        ball.position = T3DE.Vec3(ball.position.x + 0.3, ball.position.y, ball.position.z)
+        moved = many.render()
+        again = many.render()
+        fresh = T3DR.Photon(scene, dict(opts, bands=1)).render()
+        assert np.array_equal(moved.imageAs("np"), fresh.imageAs("np")) and np.array_equal(again.imageAs("np"), fresh.imageAs("np"))
+        ball.position = T3DE.Vec3(ball.position.x - 0.3, ball.position.y, ball.position.z)
+    # the default: two bands for a large frame of a small scene, one otherwise
+    big = T3DR.Photon(scene, {"width": 1024, "height": 512, "bounces": 1})
+    big.render()
+    assert big._bands() == 2 and one._bands() == 1
+    # deep trees in bands: the unchecked bands overflow, the frame is rendered again, checked
+    s = _glass_onion(T3DE)
+    glass = T3DR.Photon(s, {"width": 24, "height": 32, "bounces": 1, "samples": 2, "seed": 5, "bands": 2})
+    glass.render()
+    glass.options["bounces"] = 9
+    deep = glass.render()
+    assert np.array_equal(deep.imageAs("np"), T3DR.Photon(s, {"width": 24, "height": 32, "bounces": 9, "samples": 2, "seed": 5}).render().imageAs("np"))
+    deep2 = glass.render()
+    assert np.array_equal(deep2.imageAs("np"), deep.imageAs("np")) and deep2.rays == deep.rays
+
+
 def _glass_onion(T3DE):
     """Six nested glass spheres: trace trees that double with every bounce."""
     from raytracing_amd.scene import Camera, Light, Material, Scale, Scene, Shader, Sphere, Vec3, RGB

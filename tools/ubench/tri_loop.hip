@@ -104,6 +104,36 @@ __global__ __launch_bounds__(256) void k(const float4* __restrict__ tri_uv, int 
             ps += A * 1e-30f;
             continue;
         }
+        if (VARIANT == 4 || VARIANT == 5) {
+            // rows staged in LDS (copied once per block), read back with wave-uniform addresses (every lane gets the same
+            // 16 bytes: a broadcast, no bank conflict) into VGPRs; 4: as the compiler schedules it, 5: one pair ahead
+            __shared__ float4 rows[2 * 72];
+            if (rep == 0) {
+                for (int i = threadIdx.x; i < 2 * n_tris + 8; i += blockDim.x) rows[i] = tri_uv[i];
+                __syncthreads();
+            }
+            float4 n0 = rows[0], n1 = rows[1], n2 = rows[2], n3 = rows[3];
+            for (int k = 0; k + 1 < n_tris; k += 2) {
+                float4 ra0, rb0, ra1, rb1;
+                if (VARIANT == 5) {
+                    ra0 = n0; rb0 = n1; ra1 = n2; rb1 = n3;
+                    n0 = rows[2 * k + 4]; n1 = rows[2 * k + 5]; n2 = rows[2 * k + 6]; n3 = rows[2 * k + 7];
+                } else {
+                    ra0 = rows[2 * k + 0]; rb0 = rows[2 * k + 1]; ra1 = rows[2 * k + 2]; rb1 = rows[2 * k + 3];
+                }
+                const f2 u0 = fma2(splat(ra0.z), pt, fma2(splat(ra0.x), ps, splat(ra0.y)));
+                const f2 v0 = fma2(splat(rb0.z), pt, fma2(splat(rb0.x), ps, splat(rb0.y)));
+                const f2 w0 = (splat(1.0f) - u0) - v0;
+                const f2 m0 = {fminf(fminf(u0.x, v0.x), w0.x), fminf(fminf(u0.y, v0.y), w0.y)};
+                const f2 u1 = fma2(splat(ra1.z), pt, fma2(splat(ra1.x), ps, splat(ra1.y)));
+                const f2 v1 = fma2(splat(rb1.z), pt, fma2(splat(rb1.x), ps, splat(rb1.y)));
+                const f2 w1 = (splat(1.0f) - u1) - v1;
+                const f2 m1 = {fminf(fminf(u1.x, v1.x), w1.x), fminf(fminf(u1.y, v1.y), w1.y)};
+                A = fma2(A, splat(4.0f), fma2(step01(m0, big), splat(2.0f), step01(m1, big)));
+            }
+            ps += A * 1e-30f;
+            continue;
+        }
         for (int k = 0; k + 1 < n_tris; k += 2) {
             float4 ra0 = tri_uv[2 * k + 0], rb0 = tri_uv[2 * k + 1], ra1 = tri_uv[2 * k + 2], rb1 = tri_uv[2 * k + 3];
             if (VARIANT == 1) {  // rows do not depend on the loop index: loads hoisted, pure VALU + loop overhead
@@ -156,5 +186,8 @@ int main() {
     run<0>("scalar-loaded rows", d_rows, n_tris, d_out);
     run<2>("scalar rows, one pair ahead", d_rows, n_tris, d_out);
     run<3>("hand-scheduled asm loop", d_rows, n_tris, d_out);
+    run<1>("rows in registers (no loads)", d_rows, n_tris, d_out);
+    run<4>("rows staged in LDS", d_rows, n_tris, d_out);
+    run<5>("rows staged in LDS, one pair ahead", d_rows, n_tris, d_out);
     return 0;
 }
