@@ -303,31 +303,17 @@ __device__ __forceinline__ f2 step01(f2 m, f2 big) {
 // The hit flags of a group (at most 24 triangles) are collected as the bits of an integer kept in a float:
 //     A = 2 A + step01(min3(u, v, w))
 // so its highest set bit is the FIRST triangle hit, which is the one the reference keeps (T3DR.py:715).
-// The plane rows of a small scene (at most T3D_TAB_GROUPS groups) held in two registers per lane for the whole launch:
-// lane 2g of `a` holds n.x of group g, lane 2g + 1 its offset, `b` likewise n.y and n.z.  A row is then four v_readlane
-// away (a few issue cycles) instead of a scalar-memory request (some 200 cycles from the scalar cache).
-#define T3D_TAB_GROUPS 32
-struct PlaneTab {
-    int a, b;
-};
-template <int AX, bool NO_CULL, bool TAB = false>
+template <int AX, bool NO_CULL>
 __device__ __forceinline__ void plane_groups(const float4* __restrict__ planes, const int* __restrict__ plane_first,
                                              const float4* __restrict__ tri_uv, int g_begin, int g_end, f2 ox, f2 oy, f2 oz,
                                              f2 dx, f2 dy, f2 dz, f2 cull, f2 big, uint32_t& best0, uint32_t& best1, float& A0,
-                                             float& A1, int& bg0, int& bg1, GroupCount* gc = nullptr, PlaneTab tab = PlaneTab{0, 0}) {
+                                             float& A1, int& bg0, int& bg1, GroupCount* gc = nullptr) {
     const f2 os = AX == 0 ? oy : (AX == 1 ? oz : ox), ot = AX == 0 ? oz : (AX == 1 ? ox : oy);
     const f2 ds = AX == 0 ? dy : (AX == 1 ? dz : dx), dt = AX == 0 ? dz : (AX == 1 ? dx : dy);
     for (int g = g_begin; g < g_end; ++g) {
         // One 96-byte record per group: plane row, triangle range, and the rows of its first two triangles --
         // requested together, so a group of up to two triangles costs a single wait on scalar memory.
-        float4 rn;
-        if constexpr (TAB) {
-            rn.x = __int_as_float(__builtin_amdgcn_readlane(tab.a, 2 * g)); rn.y = __int_as_float(__builtin_amdgcn_readlane(tab.a, 2 * g + 1));
-            rn.z = __int_as_float(__builtin_amdgcn_readlane(tab.b, 2 * g)); rn.w = __int_as_float(__builtin_amdgcn_readlane(tab.b, 2 * g + 1));
-        } else {
-            rn = planes[6 * g];
-        }
-        const float4 rk = planes[6 * g + 1];
+        const float4 rn = planes[6 * g], rk = planes[6 * g + 1];
         const float4 fa0 = planes[6 * g + 2], fb0 = planes[6 * g + 3], fa1 = planes[6 * g + 4], fb1 = planes[6 * g + 5];
         const f2 dn = fma2(splat(rn.w), dz, fma2(splat(rn.z), dy, splat(rn.x) * dx));
         const f2 q = fma2(splat(rn.w), oz, fma2(splat(rn.z), oy, fma2(splat(rn.x), ox, splat(rn.y))));  // n.o - n.v0
@@ -343,7 +329,7 @@ __device__ __forceinline__ void plane_groups(const float4* __restrict__ planes, 
         const uint32_t tp0 = __float_as_uint(t.x), tp1 = __float_as_uint(t.y);
         // four of five groups are entered: their range and first rows are asked for together with the plane row (this empty
         // statement needs them, so the requests stay in front of the branch)
-        if constexpr (!TAB) asm volatile("" :: "s"(rk.w), "s"(fa0.w), "s"(fb0.w));
+        asm volatile("" :: "s"(rk.w), "s"(fa0.w), "s"(fb0.w));
         GC_ADD(gc, visited, 1);
         if (!__any((tp0 < best0) | (tp1 < best1))) continue;  // wave-uniform
         GC_ADD(gc, entered, 1);
@@ -410,10 +396,10 @@ __device__ __forceinline__ bool ray_meets_scene_box(const DevGeo& geo, V3 o, V3 
     return tn <= tf;
 }
 
-template <bool BOX_FIRST = false, bool NO_CULL = false, bool TAB = false>
+template <bool BOX_FIRST = false, bool NO_CULL = false>
 __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0, V3 d0, V3 o1, V3 d1,
                                              bool lights, bool back_cull0, bool back_cull1, Hit& out0, Hit& out1, GroupCount* gc = nullptr,
-                                             float bound0 = __builtin_inff(), float bound1 = __builtin_inff(), PlaneTab tab = PlaneTab{0, 0}) {
+                                             float bound0 = __builtin_inff(), float bound1 = __builtin_inff()) {
     // bound0 / bound1: only hits nearer than this count (non-negative; +inf: no bound).  The closest hit below the bound is
     // the closest hit, and a plane group that no ray of the wave meets below its bound is skipped like one that no ray
     // meets below its best distance.
@@ -430,9 +416,9 @@ __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0
     int bg0 = 0, bg1 = 0;
     int prim0 = -1, prim1 = -1, back0 = 0, back1 = 0;
     if (any_inside) {
-    plane_groups<0, NO_CULL, TAB>(planes, plane_first, tri_uv, 0, geo.axis_end[0], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1, gc, tab);
-    plane_groups<1, NO_CULL, TAB>(planes, plane_first, tri_uv, geo.axis_end[0], geo.axis_end[1], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1, gc, tab);
-    plane_groups<2, NO_CULL, TAB>(planes, plane_first, tri_uv, geo.axis_end[1], geo.axis_end[2], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1, gc, tab);
+    plane_groups<0, NO_CULL>(planes, plane_first, tri_uv, 0, geo.axis_end[0], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1, gc);
+    plane_groups<1, NO_CULL>(planes, plane_first, tri_uv, geo.axis_end[0], geo.axis_end[1], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1, gc);
+    plane_groups<2, NO_CULL>(planes, plane_first, tri_uv, geo.axis_end[1], geo.axis_end[2], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1, gc);
     if (A0 >= 1.0f) prim0 = first_hit_of_group(plane_first, bg0, A0);   // some group was hit (its hit bits are kept with it)
     if (A1 >= 1.0f) prim1 = first_hit_of_group(plane_first, bg1, A1);
     // Spheres and lights.  getSphereCollision (T3DR.py:572-598), Ray.getTSphere (T3DE.py:145-163).
@@ -1219,14 +1205,6 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_level(DevScene sc, GEO_PARAMS
     int items_done = 0;  // (node, light) pairs already traced     (wave-uniform)
     const float inv_L = 1.0f / (float)(L > 0 ? L : 1);
     PairList pl{PAIRS ? pair_ring_all[wc.wid] : nullptr, 0, 0u};
-#ifdef T3D_EXP_TAB
-    constexpr bool TAB = true;
-    const int* tab_src = (const int*)(planes + 6 * (sc.n_planes + 1));
-    const PlaneTab tab{tab_src[wc.lane], tab_src[64 + wc.lane]};
-#else
-    constexpr bool TAB = false;
-    const PlaneTab tab{0, 0};
-#endif
 #ifdef T3D_WAVE_TRACE
     const unsigned long long wt_start = __builtin_amdgcn_s_memrealtime();
     unsigned wt_trace = 0, wt_shadow = 0;
@@ -1270,10 +1248,10 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_level(DevScene sc, GEO_PARAMS
             // has no distance check (T3DR.py:762-778): a ray that finds nothing up to there (a Light of radius zero, a
             // start inside the Light) goes on through the whole scene.
             Hit h0, h1;
-            closest_hit2<false, true, TAB>(GEO_ARGS, sc.geo, s0.start, s0.Ld, s1.start, s1.Ld, true, false, false, h0, h1, gcp_s, s0.reach, s1.reach, tab);
+            closest_hit2<false, true>(GEO_ARGS, sc.geo, s0.start, s0.Ld, s1.start, s1.Ld, true, false, false, h0, h1, gcp_s, s0.reach, s1.reach);
             if (__any((int)(h0.prim < 0) | (int)(h1.prim < 0))) {   // wave-uniform
                 Hit g0, g1;
-                closest_hit2<false, true, TAB>(GEO_ARGS, sc.geo, s0.start, s0.Ld, s1.start, s1.Ld, true, false, false, g0, g1, gcp_s, __builtin_inff(), __builtin_inff(), tab);
+                closest_hit2<false, true>(GEO_ARGS, sc.geo, s0.start, s0.Ld, s1.start, s1.Ld, true, false, false, g0, g1, gcp_s);
                 if (h0.prim < 0) h0 = g0;
                 if (h1.prim < 0) h1 = g1;
             }
@@ -1294,8 +1272,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_level(DevScene sc, GEO_PARAMS
             load_ray<LEVEL0, ONE>(sc, rp, rays_in, chunk * cs + 64 + wc.lane, cs == 128 ? n_in : 0, queue_base, in[1]);
             const bool lights = LEVEL0 ? (rp.lights != 0) : true;
             Hit h[2];  // back faces culled iff ray.ior == 1 (T3DR.py:961)
-            closest_hit2<LEVEL0, false, TAB>(GEO_ARGS, sc.geo, in[0].o, in[0].d, in[1].o, in[1].d, lights, in[0].ior == 1.0f, in[1].ior == 1.0f, h[0], h[1], gcp_t,
-                                             __builtin_inff(), __builtin_inff(), tab);
+            closest_hit2<LEVEL0>(GEO_ARGS, sc.geo, in[0].o, in[0].d, in[1].o, in[1].d, lights, in[0].ior == 1.0f, in[1].ior == 1.0f, h[0], h[1], gcp_t);
             process_rays<LEVEL0, RING, PAIRS, ONE, 2>(sc, light_rows, rp, wc, in, h, rays_out, pool, cnt, out, ring_a, ring_b, ring_nodes, &pl);
             chunk += chunk_step;
             // the ring is private to this wave; LDS operations of one wave complete in order, the fences
@@ -2007,8 +1984,96 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
             }
         }
     }
+    // Within an axis the pieces are visited in the order of how often they hold the closest hit, most often first: a plane
+    // that cannot beat the best distance found so far is skipped by the whole wave, so the sooner the near surfaces are
+    // tested, the more of the others are skipped.  The frequencies come from a few thousand rays between random points
+    // of the triangles (float64, deterministic).  Planes that coincide -- the pieces of one group, two faces back to back
+    // -- keep their original order, which decides who wins a tie in distance (T3DR.py:715).
+    if (!want_bvh && pieces.size() > 2 && !getenv("T3D_KEEP_GROUP_ORDER")) {
+        const size_t P = pieces.size();
+        std::vector<int> piece_of_tri((size_t)s->n_tris, -1);
+        for (size_t q = 0; q < P; ++q)
+            for (int j = 0; j < pieces[q].count; ++j) piece_of_tri[groups[pieces[q].group][pieces[q].first + j]] = (int)q;
+        std::vector<double> weight(P, 0.0);
+        uint64_t rng = 0x9E3779B97F4A7C15ull;
+        auto uni = [&]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (double)(rng >> 11) * (1.0 / 9007199254740992.0); };
+        auto point_on = [&](int t, double* p) {
+            const double* v = s->tri_verts + 9 * (size_t)t;
+            double a = uni(), b = uni();
+            if (a + b > 1) { a = 1 - a; b = 1 - b; }
+            for (int k = 0; k < 3; ++k) p[k] = v[k] + a * (v[3 + k] - v[k]) + b * (v[6 + k] - v[k]);
+        };
+        const int n_samples = 4096;
+        for (int it = 0; it < n_samples && s->n_tris > 1; ++it) {
+            const int ta = (int)(uni() * s->n_tris) % s->n_tris, tb = (int)(uni() * s->n_tris) % s->n_tris;
+            double o[3], e[3], d[3];
+            point_on(ta, o); point_on(tb, e);
+            double len = 0;
+            for (int k = 0; k < 3; ++k) { d[k] = e[k] - o[k]; len += d[k] * d[k]; }
+            if (!(len > 1e-20)) continue;
+            len = sqrt(len);
+            for (int k = 0; k < 3; ++k) { d[k] /= len; o[k] += 1e-3 * len * d[k]; }
+            double best = INFINITY; int hit = -1;
+            for (int t = 0; t < s->n_tris; ++t) {
+                const Tri& T = tris[t];
+                const double dn = T.n[0] * d[0] + T.n[1] * d[1] + T.n[2] * d[2];
+                if (fabs(dn) < 1e-12) continue;
+                const double tt = (T.nv0 - (T.n[0] * o[0] + T.n[1] * o[1] + T.n[2] * o[2])) / dn;
+                if (!(tt > 0) || tt >= best) continue;
+                const double* v = s->tri_verts + 9 * (size_t)t;
+                double pnt[3], c0[3], c1[3], c2[3];
+                for (int k = 0; k < 3; ++k) pnt[k] = o[k] + tt * d[k];
+                auto edge = [&](const double* a, const double* b, double* out) {   // (b - a) x (P - a)
+                    const double u[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, w[3] = {pnt[0] - a[0], pnt[1] - a[1], pnt[2] - a[2]};
+                    out[0] = u[1] * w[2] - u[2] * w[1]; out[1] = u[2] * w[0] - u[0] * w[2]; out[2] = u[0] * w[1] - u[1] * w[0];
+                };
+                edge(v, v + 3, c0); edge(v + 3, v + 6, c1); edge(v + 6, v, c2);
+                if (c0[0] * c1[0] + c0[1] * c1[1] + c0[2] * c1[2] > 0 && c1[0] * c2[0] + c1[1] * c2[1] + c1[2] * c2[2] > 0) { best = tt; hit = t; }
+            }
+            if (hit >= 0 && piece_of_tri[hit] >= 0) weight[piece_of_tri[hit]] += 1.0;
+        }
+        // classes of coinciding planes (union-find over the pieces)
+        std::vector<int> cls(P);
+        for (size_t q = 0; q < P; ++q) cls[q] = (int)q;
+        std::function<int(int)> find = [&](int x) { while (cls[x] != x) x = cls[x] = cls[cls[x]]; return x; };
+        auto unit_plane = [&](size_t q, double* n, double& off) {
+            const Tri& F = tris[groups[pieces[q].group][0]];
+            const double len = sqrt(F.n[0] * F.n[0] + F.n[1] * F.n[1] + F.n[2] * F.n[2]);
+            if (!(len > 0)) return false;
+            for (int k = 0; k < 3; ++k) n[k] = F.n[k] / len;
+            off = F.nv0 / len;
+            return true;
+        };
+        for (size_t a = 0; a < P; ++a) {
+            double na[3], oa;
+            if (!unit_plane(a, na, oa)) continue;
+            for (size_t b = a + 1; b < P; ++b) {
+                if (pieces[a].axis != pieces[b].axis) continue;
+                double nb[3], ob;
+                if (!unit_plane(b, nb, ob)) continue;
+                const double dt = na[0] * nb[0] + na[1] * nb[1] + na[2] * nb[2];
+                const double scale = fmax(1.0, fmax(fabs(oa), fabs(ob)));
+                if (pieces[a].group == pieces[b].group || (fabs(dt) > 1 - 1e-9 && fabs(oa - (dt > 0 ? ob : -ob)) < 1e-5 * scale)) cls[find((int)b)] = find((int)a);
+            }
+        }
+        std::vector<double> cls_weight(P, 0.0);
+        std::vector<int> cls_first(P, (int)P);
+        for (size_t q = 0; q < P; ++q) { const int r = find((int)q); cls_weight[r] += weight[q]; cls_first[r] = std::min(cls_first[r], (int)q); }
+        std::vector<int> idx(P);
+        for (size_t q = 0; q < P; ++q) idx[q] = (int)q;
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
+            if (pieces[a].axis != pieces[b].axis) return pieces[a].axis < pieces[b].axis;
+            const int ra = find(a), rb = find(b);
+            if (ra == rb) return a < b;
+            if (cls_weight[ra] != cls_weight[rb]) return cls_weight[ra] > cls_weight[rb];
+            return cls_first[ra] < cls_first[rb];
+        });
+        std::vector<Piece> sorted(P);
+        for (size_t q = 0; q < P; ++q) sorted[q] = pieces[idx[q]];
+        pieces.swap(sorted);
+    }
     const size_t G = pieces.size();
-    std::vector<float4> planes(6 * (G + 1) + T3D_TAB_GROUPS, make_float4(0.f, 0.f, 0.f, 0.f));   // group records, then the plane rows as a register table
+    std::vector<float4> planes(6 * (G + 1), make_float4(0.f, 0.f, 0.f, 0.f));
     std::vector<int> plane_first(G + 1, 0);
     std::vector<float4> tri_uv((size_t)2 * (s->n_tris + 1), make_float4(0.f, 0.f, 0.f, 0.f));
     std::vector<float4> tri_n((size_t)s->n_tris + 1, make_float4(0.f, 0.f, 0.f, 0.f));
@@ -2046,13 +2111,6 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
             }
         }
         plane_first[G] = k;
-        {   // PlaneTab: (n.x, offset) of group g at floats 2g, 2g + 1; (n.y, n.z) at 64 + 2g, 64 + 2g + 1
-            float* tabf = (float*)&planes[6 * (G + 1)];
-            for (size_t g = 0; g < G && g < T3D_TAB_GROUPS; ++g) {
-                tabf[2 * g] = planes[6 * g].x; tabf[2 * g + 1] = planes[6 * g].y;
-                tabf[64 + 2 * g] = planes[6 * g].z; tabf[64 + 2 * g + 1] = planes[6 * g].w;
-            }
-        }
         if (want_bvh) {
             for (int t = 0; t < s->n_tris; ++t) {
                 const Tri& T = tris[t];
