@@ -164,6 +164,16 @@ const char* t3d_last_error(const t3d_ctx* ctx); /* ctx may be NULL: error of a f
 int t3d_upload_scene(t3d_ctx* ctx, const t3d_scene_desc* scene);
 
 /*
+ * The uploaded scene again after spheres, Lights or the camera have moved: their centres, radii (scale), strengths, the
+ * light positions and the camera are taken from `scene`, everything else stays as uploaded -- no plane grouping, no
+ * hierarchy build; the hierarchy of a large scene is refitted (its boxes computed again bottom-up, its shape kept).
+ * For callers that look at a live scene before every query (picking while the user drags a light, explorer.py:1346-1392,
+ * T3DR.py:671-705).  `scene` must describe the uploaded scene otherwise -- same objects of the same kinds, same
+ * triangles, same shaders; differing counts or kinds are refused with T3D_E_INVALID, changed triangles are not noticed.
+ */
+int t3d_update_scene(t3d_ctx* ctx, const t3d_scene_desc* scene);
+
+/*
  * Render nrows image rows starting at row0 (consecutive, or every opts->row_stride-th row for
  * interleaved multi-GPU tiles): Photon.renderStripe (T3DR.py:1183-1242) with everything
  * under it (pixelToVector, getRay, trace, computeColor, getDirectLight, getFirstCollision).

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("T3D_HIP_LIB") or os.path.join(os.path.dirname(os.path
 ABI_VERSION = 7
 
 SYMBOLS = ("t3d_abi_version", "t3d_device_count", "t3d_create", "t3d_destroy", "t3d_last_error",
-           "t3d_upload_scene", "t3d_render_rows", "t3d_render_rows_device", "t3d_trace_pixel", "t3d_trace_ray",
+           "t3d_upload_scene", "t3d_update_scene", "t3d_render_rows", "t3d_render_rows_device", "t3d_trace_pixel", "t3d_trace_ray",
            "t3d_closest_hits", "t3d_last_call_stats", "t3d_set_timing", "t3d_set_accel", "t3d_set_rounds", "t3d_set_cancel",
            "t3d_render_rows_async", "t3d_host_alloc", "t3d_host_free", "t3d_render_frame_multi",
            "t3d_render_rows_device_static", "t3d_graph_counters", "t3d_render_rows_device_split", "t3d_render_rows_async_split",
@@ -90,6 +90,8 @@ def load():
     lib.t3d_last_error.argtypes = [C.c_void_p]
     lib.t3d_upload_scene.restype = C.c_int
     lib.t3d_upload_scene.argtypes = [C.c_void_p, P(SceneDesc)]
+    lib.t3d_update_scene.restype = C.c_int
+    lib.t3d_update_scene.argtypes = [C.c_void_p, P(SceneDesc)]
     lib.t3d_render_rows.restype = C.c_int
     lib.t3d_render_rows.argtypes = [C.c_void_p, P(Opts), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, P(Stats)]
@@ -233,6 +235,12 @@ class Context:
     def upload(self, flat: FlatScene):
         desc = flat.as_desc()
         self._check(self._lib.t3d_upload_scene(self._h, C.byref(desc)), "t3d_upload_scene")
+        self.flat = flat
+
+    def update(self, flat: FlatScene):
+        """The uploaded scene with spheres, Lights or the camera moved (``t3d_update_scene``): no grouping, no build."""
+        desc = flat.as_desc()
+        self._check(self._lib.t3d_update_scene(self._h, C.byref(desc)), "t3d_update_scene")
         self.flat = flat
 
     def render_rows(self, options: dict, seed: int = 0, row0: int = 0, nrows: int | None = None,

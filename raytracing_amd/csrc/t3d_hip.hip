@@ -1678,6 +1678,15 @@ struct t3d_ctx {
     void* d_tri_meta = nullptr; void* d_spheres = nullptr; void* d_lights = nullptr;
     void* d_shaders = nullptr; void* d_obj_ior = nullptr; void* d_prim_info = nullptr;
     int n_objects = 0, n_sphere_objs = 0, n_light_objs = 0;
+    // kept for t3d_update_scene (the same scene with spheres, Lights or the camera moved)
+    std::vector<int> obj_types;               // T3D_OBJ_* of every object as uploaded
+    std::vector<DevSphere> h_spheres;         // the spheres and Lights as uploaded (object, shader, kind)
+    double tri_lo[3] = {0, 0, 0}, tri_hi[3] = {0, 0, 0};   // bounds of the triangles
+    int up_tris = 0, up_shaders = 0, up_lights = 0;
+    std::vector<float4> up_rows;              // t3d_update_scene: host staging that must outlive its asynchronous copies
+    std::vector<DevLight> up_light_rows;
+    LbvhWork lbvh_work;                       // working arrays of the hierarchy build (LBVH scenes)
+    void* d_lbvh_verts = nullptr; void* d_lbvh_tri_ab = nullptr;
     // work buffers: one set for image bands, a small one for the tree of a single ray (t3d_trace_pixel / t3d_trace_ray), so
     // that a picked pixel neither frees the band buffers nor invalidates the launch graphs that hold their addresses
     Work work, single_work;
@@ -1816,6 +1825,9 @@ extern "C" int t3d_create(int device, t3d_ctx** out) {
 }
 
 static void free_scene(t3d_ctx* c) {
+    c->lbvh_work.release();
+    hipFree(c->d_lbvh_verts); hipFree(c->d_lbvh_tri_ab);
+    c->d_lbvh_verts = c->d_lbvh_tri_ab = nullptr;
     hipFree(c->d_planes); hipFree(c->d_plane_first); hipFree(c->d_tri_uv); hipFree(c->d_tri_n);
     hipFree(c->d_bvh_nodes); hipFree(c->d_bvh_leaves); hipFree(c->d_bvh_spill);
     c->d_bvh_nodes = c->d_bvh_leaves = c->d_bvh_spill = nullptr; c->use_bvh = false;
@@ -1873,6 +1885,65 @@ static int upload(t3d_ctx* c, void** dst, const std::vector<T>& v) {
     return T3D_OK;
 }
 
+// Pieces of the device scene that t3d_upload_scene and t3d_update_scene both make.
+// scene bounds for the camera-ray pre-test, padded outward by 1e-4 of their size (tri_lo / tri_hi: bounds of the triangles)
+static void set_scene_box(t3d_ctx* c, const std::vector<DevSphere>& spheres) {
+    double lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) { lo[a] = c->tri_lo[a]; hi[a] = c->tri_hi[a]; }
+    for (const DevSphere& sp : spheres) {
+        const double r = sqrt((double)sp.r2) * 1.000001, cc[3] = {sp.cx, sp.cy, sp.cz};
+        for (int a = 0; a < 3; ++a) { lo[a] = fmin(lo[a], cc[a] - r); hi[a] = fmax(hi[a], cc[a] + r); }
+    }
+    for (int a = 0; a < 3; ++a) {
+        const double pad = 1e-4 * fmax(fmax(fabs(lo[a]), fabs(hi[a])), hi[a] - lo[a]) + 1e-30;
+        c->sc.geo.box_lo[a] = lo[a] <= hi[a] ? (float)(lo[a] - pad) : 1.0f;   // no primitives: an empty box
+        c->sc.geo.box_hi[a] = lo[a] <= hi[a] ? (float)(hi[a] + pad) : -1.0f;
+    }
+}
+static void set_camera(DevScene& d, const t3d_scene_desc* s) {
+    for (int k = 0; k < 3; ++k) d.cam.pos[k] = (float)s->cam_pos[k];
+    // Euler.toMatrix (T3DE.py:70-94) in float64, rounded once
+    const double cx = cos(s->cam_euler[0]), sx = sin(s->cam_euler[0]), cy = cos(s->cam_euler[1]), sy = sin(s->cam_euler[1]);
+    const double cz = cos(s->cam_euler[2]), sz = sin(s->cam_euler[2]);
+    const double m[9] = {cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx,
+                         sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx,
+                         -sy, cy * sx, cy * cx};
+    for (int k = 0; k < 9; ++k) d.cam.m[k] = (float)m[k];
+    d.cam.zlen = (float)s->cam_zlen;
+}
+// the light list, and the sum over the lights of colour * 0.6 with saturating adds (T3DR.py:893)
+static std::vector<DevLight> make_lights(DevScene& d, const t3d_scene_desc* s) {
+    std::vector<DevLight> lights((size_t)s->n_lights);
+    double lc[3] = {0, 0, 0};
+    for (int l = 0; l < s->n_lights; ++l) {
+        lights[l] = DevLight{(float)s->light_pos[3 * l], (float)s->light_pos[3 * l + 1], (float)s->light_pos[3 * l + 2], (float)s->light_strength[l]};
+        for (int ch = 0; ch < 3; ++ch) { lc[ch] += s->light_color[3 * l + ch] * 0.6; if (lc[ch] > 255) lc[ch] = 255; }
+    }
+    for (int k = 0; k < 3; ++k) d.light_color[k] = (float)lc[k];
+    return lights;
+}
+// the three prim_info rows of a sphere or Light
+static void sphere_rows(const DevSphere& sp, const t3d_scene_desc* s, float4* rows) {
+    auto ib = [](int v) { return __builtin_bit_cast(float, v); };
+    const float rough = (float)s->shader_rough[sp.shader], refl = (float)s->shader_refl[sp.shader];
+    rows[0] = make_float4(sp.cx, sp.cy, sp.cz, (float)s->obj_ior[sp.obj]);
+    rows[1] = make_float4(ib(sp.obj), ib(-1), ib(sp.shader), ib(2 | (sp.is_light ? 1 : 0)));
+    rows[2] = make_float4(rough, refl, sp.strength, sp.is_light ? 1.0f : 1.0f - refl);
+}
+static const char* not_finite(const t3d_scene_desc* s, bool triangles) {
+    auto finite = [](const double* p, size_t n) { if (p) for (size_t i = 0; i < n; ++i) if (!std::isfinite(p[i])) return false; return true; };
+    return triangles && !finite(s->tri_verts, (size_t)s->n_tris * 9) ? "a triangle corner"
+         : !finite(s->obj_center, (size_t)s->n_objects * 3) ? "an object position"
+         : !finite(s->obj_radius, (size_t)s->n_objects) ? "an object radius"
+         : !finite(s->light_pos, (size_t)s->n_lights * 3) ? "a light position"
+         : !finite(s->cam_pos, 3) || !finite(s->cam_euler, 3) || !finite(&s->cam_zlen, 1) ? "the camera"
+         : !finite(s->obj_ior, (size_t)s->n_objects) || !finite(s->obj_strength, (size_t)s->n_objects) ? "an object's ior or strength"
+         : !finite(s->shader_color, (size_t)s->n_shaders * 3) || !finite(s->shader_rough, (size_t)s->n_shaders) ||
+           !finite(s->shader_refl, (size_t)s->n_shaders) || !finite(s->shader_emis, (size_t)s->n_shaders) ? "a shader value"
+         : !finite(s->light_strength, (size_t)s->n_lights) || !finite(s->light_color, (size_t)s->n_lights * 3) ? "a light's strength or colour"
+         : nullptr;
+}
+
 extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
     if (!c) return T3D_E_INVALID;
     if (!s || s->n_objects < 0 || s->n_tris < 0 || s->n_shaders < 0 || s->n_lights < 0) { c->err = "t3d_upload_scene: bad description"; return T3D_E_INVALID; }
@@ -1886,21 +1957,8 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
                             : s->n_lights > 0 && (!s->light_pos || !s->light_strength || !s->light_color) ? "a light array" : nullptr;
         if (missing) { c->err = std::string("t3d_upload_scene: ") + missing + " is null"; return T3D_E_INVALID; }
     }
-    {
-        // geometry that is not a finite number has no place in a hierarchy or a plane group: refuse it by name
-        auto finite = [](const double* p, size_t n) { if (p) for (size_t i = 0; i < n; ++i) if (!std::isfinite(p[i])) return false; return true; };
-        const char* bad = !finite(s->tri_verts, (size_t)s->n_tris * 9) ? "a triangle corner"
-                        : !finite(s->obj_center, (size_t)s->n_objects * 3) ? "an object position"
-                        : !finite(s->obj_radius, (size_t)s->n_objects) ? "an object radius"
-                        : !finite(s->light_pos, (size_t)s->n_lights * 3) ? "a light position"
-                        : !finite(s->cam_pos, 3) || !finite(s->cam_euler, 3) || !finite(&s->cam_zlen, 1) ? "the camera"
-                        : !finite(s->obj_ior, (size_t)s->n_objects) || !finite(s->obj_strength, (size_t)s->n_objects) ? "an object's ior or strength"
-                        : !finite(s->shader_color, (size_t)s->n_shaders * 3) || !finite(s->shader_rough, (size_t)s->n_shaders) ||
-                          !finite(s->shader_refl, (size_t)s->n_shaders) || !finite(s->shader_emis, (size_t)s->n_shaders) ? "a shader value"
-                        : !finite(s->light_strength, (size_t)s->n_lights) || !finite(s->light_color, (size_t)s->n_lights * 3) ? "a light's strength or colour"
-                        : nullptr;
-        if (bad) { c->err = std::string("t3d_upload_scene: ") + bad + " is not finite"; return T3D_E_INVALID; }
-    }
+    // geometry that is not a finite number has no place in a hierarchy or a plane group: refuse it by name
+    if (const char* bad = not_finite(s, true)) { c->err = std::string("t3d_upload_scene: ") + bad + " is not finite"; return T3D_E_INVALID; }
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_scene(c);
@@ -2160,12 +2218,7 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
         shaders[k] = DevShader{(float)s->shader_color[3 * k], (float)s->shader_color[3 * k + 1], (float)s->shader_color[3 * k + 2],
                                (float)s->shader_rough[k], (float)s->shader_refl[k], (float)s->shader_emis[k], 0.f, 0.f};
     }
-    std::vector<DevLight> lights((size_t)s->n_lights);
-    double lc[3] = {0, 0, 0};
-    for (int l = 0; l < s->n_lights; ++l) {
-        lights[l] = DevLight{(float)s->light_pos[3 * l], (float)s->light_pos[3 * l + 1], (float)s->light_pos[3 * l + 2], (float)s->light_strength[l]};
-        for (int ch = 0; ch < 3; ++ch) { lc[ch] += s->light_color[3 * l + ch] * 0.6; if (lc[ch] > 255) lc[ch] = 255; }
-    }
+    std::vector<DevLight> lights = make_lights(c->sc, s);
     std::vector<float4> prim_info(3 * ((size_t)s->n_tris + spheres.size()));
     {
         auto ib = [](int v) { return __builtin_bit_cast(float, v); };
@@ -2182,14 +2235,7 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
             prim_info[3 * (size_t)k + 1] = make_float4(ib(m.x), ib(m.y), ib(m.z), ib(emitter ? 1 : 0));
             prim_info[3 * (size_t)k + 2] = make_float4(sh.rough, sh.refl, sh.emis, emitter ? 1.0f : 1.0f - sh.refl);
         }
-        for (size_t q = 0; q < spheres.size(); ++q) {
-            const DevSphere& sp = spheres[q];
-            const DevShader& sh = shaders[sp.shader];
-            const size_t k = (size_t)s->n_tris + q;
-            prim_info[3 * k + 0] = make_float4(sp.cx, sp.cy, sp.cz, obj_ior[sp.obj]);
-            prim_info[3 * k + 1] = make_float4(ib(sp.obj), ib(-1), ib(sp.shader), ib(2 | (sp.is_light ? 1 : 0)));
-            prim_info[3 * k + 2] = make_float4(sh.rough, sh.refl, sp.strength, sp.is_light ? 1.0f : 1.0f - sh.refl);
-        }
+        for (size_t q = 0; q < spheres.size(); ++q) sphere_rows(spheres[q], s, &prim_info[3 * ((size_t)s->n_tris + q)]);
     }
     int rc;
     if ((rc = upload(c, &c->d_prim_info, prim_info)) || (rc = upload(c, &c->d_planes, planes)) || (rc = upload(c, &c->d_plane_first, plane_first)) || (rc = upload(c, &c->d_tri_uv, tri_uv)) ||
@@ -2220,9 +2266,9 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
         float4* nodes = nullptr;
         float4* leaves = nullptr;
         hipError_t e = lbvh_build(c->stream, (const float*)d_verts, (const float4*)d_tri_ab, s->n_tris, (const DevSphere*)c->d_spheres,
-                                  (int)spheres.size(), &nodes, &leaves);
-        hipFree(d_verts); hipFree(d_tri_ab);
-        if (e != hipSuccess) { c->err = std::string("t3d_upload_scene: LBVH build failed: ") + hipGetErrorString(e); return T3D_E_DEVICE; }
+                                  (int)spheres.size(), &nodes, &leaves, &c->lbvh_work);
+        if (e != hipSuccess) { hipFree(d_verts); hipFree(d_tri_ab); c->err = std::string("t3d_upload_scene: LBVH build failed: ") + hipGetErrorString(e); return T3D_E_DEVICE; }
+        c->d_lbvh_verts = d_verts; c->d_lbvh_tri_ab = d_tri_ab;   // kept for a refit (t3d_update_scene)
         c->d_bvh_nodes = nodes; c->d_bvh_leaves = leaves;
         // deep ends of traversal stacks, one piece per wave the traversal kernels can have in flight (never touched by the
         // benchmark workloads, whose stacks stay within the LDS part)
@@ -2234,36 +2280,74 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
     d.bvh.spill = (int*)c->d_bvh_spill;
     d.geo.axis_end[0] = axis_count[0]; d.geo.axis_end[1] = axis_count[0] + axis_count[1]; d.geo.axis_end[2] = (int)G;
     d.geo.n_tris = s->n_tris; d.geo.n_spheres = (int)spheres.size();
-    {   // scene bounds for the camera-ray pre-test, padded outward by 1e-4 of their size
-        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (size_t q = 0; q < (size_t)s->n_tris * 9; ++q) { lo[q % 3] = fmin(lo[q % 3], s->tri_verts[q]); hi[q % 3] = fmax(hi[q % 3], s->tri_verts[q]); }
-        for (const DevSphere& sp : spheres) {
-            const double r = sqrt((double)sp.r2) * 1.000001, cc[3] = {sp.cx, sp.cy, sp.cz};
-            for (int a = 0; a < 3; ++a) { lo[a] = fmin(lo[a], cc[a] - r); hi[a] = fmax(hi[a], cc[a] + r); }
-        }
-        for (int a = 0; a < 3; ++a) {
-            const double pad = 1e-4 * fmax(fmax(fabs(lo[a]), fabs(hi[a])), hi[a] - lo[a]) + 1e-30;
-            d.geo.box_lo[a] = lo[a] <= hi[a] ? (float)(lo[a] - pad) : 1.0f;   // no primitives: an empty box
-            d.geo.box_hi[a] = lo[a] <= hi[a] ? (float)(hi[a] + pad) : -1.0f;
-        }
-    }
+    for (int a = 0; a < 3; ++a) { c->tri_lo[a] = INFINITY; c->tri_hi[a] = -INFINITY; }
+    for (size_t q = 0; q < (size_t)s->n_tris * 9; ++q) { c->tri_lo[q % 3] = fmin(c->tri_lo[q % 3], s->tri_verts[q]); c->tri_hi[q % 3] = fmax(c->tri_hi[q % 3], s->tri_verts[q]); }
+    set_scene_box(c, spheres);
     d.n_planes = (int)G; d.n_tris = s->n_tris; d.n_spheres = (int)spheres.size(); d.n_lights = s->n_lights; d.n_shaders = s->n_shaders;
     d.tri_n = (const float4*)c->d_tri_n; d.tri_meta = (const int4*)c->d_tri_meta;
     d.lights = (const DevLight*)c->d_lights; d.shaders = (const DevShader*)c->d_shaders; d.obj_ior = (const float*)c->d_obj_ior;
     d.prim_info = (const float4*)c->d_prim_info;
-    for (int k = 0; k < 3; ++k) { d.cam.pos[k] = (float)s->cam_pos[k]; d.light_color[k] = (float)lc[k]; }
-    {   // Euler.toMatrix (T3DE.py:70-94) in float64, rounded once
-        double cx = cos(s->cam_euler[0]), sx = sin(s->cam_euler[0]), cy = cos(s->cam_euler[1]), sy = sin(s->cam_euler[1]);
-        double cz = cos(s->cam_euler[2]), sz = sin(s->cam_euler[2]);
-        double m[9] = {cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx,
-                       sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx,
-                       -sy, cy * sx, cy * cx};
-        for (int k = 0; k < 9; ++k) d.cam.m[k] = (float)m[k];
-    }
-    d.cam.zlen = (float)s->cam_zlen;
+    set_camera(d, s);
     c->n_objects = s->n_objects;
+    c->obj_types.assign(s->obj_type, s->obj_type + s->n_objects);
+    c->h_spheres = spheres;
+    c->up_tris = s->n_tris; c->up_shaders = s->n_shaders; c->up_lights = s->n_lights;
     c->has_scene = true;
     c->scene_gen++;
+    return T3D_OK;
+}
+
+// The uploaded scene again with spheres, Lights or the camera moved (centres, radii, strengths, light positions, the
+// camera): nothing is grouped or built again, the hierarchy of a large scene is refitted.  The caller vouches for the
+// rest of the description -- the triangles, the shaders, the objects' kinds -- being what was uploaded; what can be
+// checked cheaply (the counts, the kinds) is.
+extern "C" int t3d_update_scene(t3d_ctx* c, const t3d_scene_desc* s) {
+    if (!c) return T3D_E_INVALID;
+    if (!c->has_scene) { c->err = "t3d_update_scene: no scene uploaded"; return T3D_E_INVALID; }
+    if (!s || s->n_objects != c->n_objects || s->n_tris != c->up_tris || s->n_shaders != c->up_shaders || s->n_lights != c->up_lights) {
+        c->err = "t3d_update_scene: not the uploaded scene (counts differ): upload it";
+        return T3D_E_INVALID;
+    }
+    if ((s->n_objects > 0 && (!s->obj_type || !s->obj_center || !s->obj_radius || !s->obj_ior || !s->obj_strength)) ||
+        (s->n_lights > 0 && (!s->light_pos || !s->light_strength || !s->light_color)) ||
+        (s->n_shaders > 0 && (!s->shader_rough || !s->shader_refl || !s->shader_color || !s->shader_emis))) {
+        c->err = "t3d_update_scene: an array is null";
+        return T3D_E_INVALID;
+    }
+    for (int o = 0; o < s->n_objects; ++o)
+        if (s->obj_type[o] != c->obj_types[o]) { c->err = "t3d_update_scene: not the uploaded scene (an object's kind differs): upload it"; return T3D_E_INVALID; }
+    if (const char* bad = not_finite(s, false)) { c->err = std::string("t3d_update_scene: ") + bad + " is not finite"; return T3D_E_INVALID; }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->shadow_stream));
+    // (the stream is idle now: the staging vectors of the previous update are free again)
+    std::vector<DevSphere>& spheres = c->h_spheres;
+    std::vector<float4>& rows = c->up_rows;
+    rows.resize(3 * spheres.size());
+    for (size_t q = 0; q < spheres.size(); ++q) {
+        DevSphere& sp = spheres[q];
+        const int o = sp.obj;
+        sp.cx = (float)s->obj_center[3 * o]; sp.cy = (float)s->obj_center[3 * o + 1]; sp.cz = (float)s->obj_center[3 * o + 2];
+        sp.r2 = (float)(s->obj_radius[o] * s->obj_radius[o]);
+        sp.strength = (float)s->obj_strength[o];
+        sphere_rows(sp, s, &rows[3 * q]);
+    }
+    c->up_light_rows = make_lights(c->sc, s);
+    const std::vector<DevLight>& lights = c->up_light_rows;
+    if (!spheres.empty()) {
+        HIPCHK(c, hipMemcpyAsync(c->d_spheres, spheres.data(), sizeof(DevSphere) * spheres.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync((float4*)c->d_prim_info + 3 * (size_t)c->up_tris, rows.data(), sizeof(float4) * rows.size(), hipMemcpyHostToDevice, c->stream));
+    }
+    if (!lights.empty()) HIPCHK(c, hipMemcpyAsync(c->d_lights, lights.data(), sizeof(DevLight) * lights.size(), hipMemcpyHostToDevice, c->stream));
+    set_scene_box(c, spheres);
+    set_camera(c->sc, s);
+    if (c->use_bvh) {
+        hipError_t e = lbvh_refit(c->stream, c->lbvh_work, (const float*)c->d_lbvh_verts, (const float4*)c->d_lbvh_tri_ab, c->up_tris,
+                                  (const DevSphere*)c->d_spheres, (int)spheres.size(), (float4*)c->d_bvh_nodes, (float4*)c->d_bvh_leaves);
+        if (e != hipSuccess) { c->err = std::string("t3d_update_scene: refit failed: ") + hipGetErrorString(e); return T3D_E_DEVICE; }
+    }
+    // not waited for: whatever the caller does next on this context is queued behind the copies and the refit
+    c->scene_gen++;   // launch graphs hold the camera and the bounds by value
     return T3D_OK;
 }
 

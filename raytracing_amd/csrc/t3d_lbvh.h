@@ -26,6 +26,7 @@ struct LbvhWork {
     float4* box_hi = nullptr;
     int* flags = nullptr;        // [N-1] arrival counters of the refit
     int* bounds = nullptr;       // [6] scene bounds as order-preserving ints
+    int sorted = 0;              // keys[sorted] / vals[sorted] hold the sorted order (kept for lbvh_refit)
     void release() {
         hipFree(prim_lo); hipFree(prim_hi); hipFree(keys[0]); hipFree(keys[1]); hipFree(vals[0]); hipFree(vals[1]);
         hipFree(hist); hipFree(sums); hipFree(parent); hipFree(kids); hipFree(box_lo); hipFree(box_hi); hipFree(flags); hipFree(bounds);
@@ -324,8 +325,9 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_leaves(const int* __restric
 // Build the hierarchy over n_tris triangles (vertices in device order, 9 floats each; d_tri_ab their 64-byte
 // intersection records in the same order) and n_spheres spheres; *out_nodes receives n - 1 traversal nodes and
 // *out_leaves n leaf records of 64 bytes each (hipMalloc, owned by the caller).  Needs n >= 2.
+// `keep`: where the build's working arrays go instead of being released, for lbvh_refit.
 static hipError_t lbvh_build(hipStream_t st, const float* d_verts, const float4* d_tri_ab, int n_tris, const DevSphere* d_spheres,
-                             int n_spheres, float4** out_nodes, float4** out_leaves) {
+                             int n_spheres, float4** out_nodes, float4** out_leaves, LbvhWork* keep = nullptr) {
     const int n = n_tris + n_spheres;
     LbvhWork w;
     hipError_t e = hipSuccess;
@@ -373,8 +375,29 @@ static hipError_t lbvh_build(hipStream_t st, const float* d_verts, const float4*
     LB(hipGetLastError());
     LB(hipStreamSynchronize(st));
 #undef LB
-    w.release();
+    w.sorted = cur;
+    if (keep) *keep = w; else w.release();
     *out_nodes = nodes;
     *out_leaves = leaves;
     return hipSuccess;
+}
+
+// The same hierarchy after primitives have moved (spheres, Lights: the triangles are the caller's promise not to have):
+// boxes of the primitives again, boxes of the nodes bottom-up, records packed again.  The tree keeps its shape -- a sphere
+// that has travelled far sits in a larger box than a new build would give it, which costs visits, never hits.
+static hipError_t lbvh_refit(hipStream_t st, LbvhWork& w, const float* d_verts, const float4* d_tri_ab, int n_tris, const DevSphere* d_spheres,
+                             int n_spheres, float4* nodes, float4* leaves) {
+    const int n = n_tris + n_spheres;
+    auto blocks = [](int k) { return dim3((unsigned)((k + LBVH_BLOCK - 1) / LBVH_BLOCK)); };
+    hipError_t e = hipMemsetAsync(w.flags, 0, sizeof(int) * (n - 1), st);
+    if (e != hipSuccess) return e;
+    const int nb = (n + LBVH_BLOCK - 1) / LBVH_BLOCK;
+    hipLaunchKernelGGL(k_lbvh_bounds, dim3((unsigned)(nb > 1024 ? 1024 : nb)), dim3(LBVH_BLOCK), 0, st, d_verts, n_tris, d_spheres, n_spheres,
+                       w.prim_lo, w.prim_hi, w.bounds);
+    hipLaunchKernelGGL(k_lbvh_refit, blocks(n), dim3(LBVH_BLOCK), 0, st, w.vals[w.sorted], n, w.prim_lo, w.prim_hi, w.kids, w.parent, w.box_lo,
+                       w.box_hi, w.flags);
+    hipLaunchKernelGGL(k_lbvh_pack, blocks(n - 1), dim3(LBVH_BLOCK), 0, st, w.vals[w.sorted], n, w.prim_lo, w.prim_hi, w.kids, w.box_lo, w.box_hi,
+                       nodes);
+    hipLaunchKernelGGL(k_lbvh_leaves, blocks(n), dim3(LBVH_BLOCK), 0, st, w.vals[w.sorted], n, n_tris, d_tri_ab, d_spheres, leaves);
+    return hipGetLastError();
 }

@@ -31,7 +31,7 @@ from collections.abc import Mapping
 import numpy as np
 
 from . import _native
-from .flatten import flatten_scene
+from .flatten import FlattenCache, flatten_scene
 from .scene import RGB, Ray, Scale, TraceTreeNode, Vec3
 
 
@@ -159,6 +159,7 @@ class Photon:
         self._baked = None
         self._uploaded_digest = None
         self.uploads = 0           # scene uploads so far (a re-flattening with an unchanged digest is not one)
+        self.updates = 0           # of which in place: only spheres, Lights or the camera had moved
         self._multi = []           # [context, digest of its scene] per GPU when options['gpus'] > 1
         self._multi_devices = None
         self._helpers = []         # [context, digest of its scene]: trace the other bands of a frame (options['bands'])
@@ -176,6 +177,7 @@ class Photon:
         self._scene = scene
         self._flat = None
         self._baked = None
+        self._cache = FlattenCache()
 
     @property
     def transformedScene(self):
@@ -219,12 +221,19 @@ class Photon:
         if self._scene.camera is None:
             raise NoBoundCameraError()
         if force_flatten or self._flat is None or not self.options["transformBefore"]:
-            flat = flatten_scene(self._scene)
+            # only what changed since the last look is baked again; a render compares the meshes entry by entry, a query
+            # that looks at a live scene before every ray (picking) goes by the objects' signatures
+            before = self._flat.digest() if self._flat is not None else None
+            flat = flatten_scene(self._scene, self._cache, thorough=force_flatten or self._flat is None)
             digest = flat.digest()
-            # an unchanged scene keeps its device copy (plane groups, hierarchy): a render or a picking loop over a
-            # scene that is not being edited pays for the flattening only
+            # an unchanged scene keeps its device copy (plane groups, hierarchy); one in which only spheres, Lights or the
+            # camera moved has it updated in place (no grouping, no hierarchy build)
             if digest != self._uploaded_digest:
-                self._context().upload(flat)
+                if self._cache.change == "moved" and before is not None and before == self._uploaded_digest:
+                    self._context().update(flat)
+                    self.updates += 1
+                else:
+                    self._context().upload(flat)
                 self._uploaded_digest = digest
                 self.uploads += 1
             self._flat = flat
@@ -447,7 +456,7 @@ class Photon:
                 c.close()
             self._multi = [[_native.Context(d), None] for d in devices]
             self._multi_devices = devices
-        flat = flatten_scene(self._scene)
+        flat = flatten_scene(self._scene, self._cache, thorough=True)
         digest = flat.digest()
         for slot in self._multi:
             if slot[1] != digest:

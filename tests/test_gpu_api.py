@@ -380,6 +380,59 @@ def test_photon_render_in_bands():
     assert np.array_equal(deep2.imageAs("np"), deep.imageAs("np")) and deep2.rays == deep.rays
 
 
+@pytest.mark.parametrize("workload", ["cornell", "monkey"])
+def test_live_scene_updates_in_place_when_only_spheres_lights_or_the_camera_move(workload):
+    """Picking on a live scene (transformBefore False, explorer.py:324-355): when only spheres, Lights or the camera moved
+    since the last query the device copy is updated in place (t3d_update_scene: no plane grouping; the hierarchy of the
+    monkey scene is refitted); a moved mesh is uploaded.  Picks, trees and renders equal those of a fresh Photon."""
+    import T3DE
+    import T3DR
+    from raytracing_amd.workloads import cornell_scene
+    scene = cornell_scene(with_light=True, suzanne=workload == "monkey")
+    opts = {"width": 64, "height": 48, "bounces": 2, "samples": 1, "seed": 2, "transformBefore": False}
+    live = T3DR.Photon(scene, dict(opts))
+
+    def picks(photon):
+        out = []
+        for x, y in ((32, 24), (20, 30), (44, 30), (30, 12), (5, 5)):
+            hit = photon.getFirstCollision(photon.getRay(photon.pixelToVector(x, y)), True, False)
+            out.append((hit["object"].id if hit["object"] else None, None if hit["t"] is None else round(hit["t"], 4)))
+        return out
+
+    first = picks(live)
+    assert live.uploads == 1 and live.updates == 0
+    assert picks(live) == first and live.uploads == 1                       # nothing moved: nothing sent
+    light = next(o for o in scene.objects if o.type == "light")
+    ball = next(o for o in scene.objects if o.type == "sphere")
+    light.position = T3DE.Vec3(0.4, 2.6, 0.8)
+    ball.position = T3DE.Vec3(ball.position.x + 0.9, ball.position.y + 0.5, ball.position.z - 0.3)
+    ball.scale = T3DE.Scale(2.4, 2.4, 2.4)
+    scene.camera.position = T3DE.Vec3(0.3, 0.1, -10.5)
+    moved = picks(live)
+    assert live.uploads == 2 and live.updates == 1
+    fresh = T3DR.Photon(scene, dict(opts))
+    assert moved == picks(fresh) and moved != first
+    a, b = live.render(), fresh.render()
+    assert np.array_equal(a.imageAs("np"), b.imageAs("np")) and a.rays == b.rays
+    assert live.uploads == 2
+    # a mesh moves: an upload
+    mesh = next(o for o in scene.objects if o.type == "mesh" and o.name != "Box")
+    mesh.position = T3DE.Vec3(mesh.position.x - 0.4, mesh.position.y, mesh.position.z)
+    after = picks(live)
+    assert live.uploads == 3 and live.updates == 1 and after == picks(T3DR.Photon(scene, dict(opts)))
+    # a single coordinate edited in place is seen by the next render (which compares the meshes entry by entry)
+    mesh.mesh.vertices[1].y += 0.25
+    c, d = live.render(), T3DR.Photon(scene, dict(opts)).render()
+    assert live.uploads == 4 and np.array_equal(c.imageAs("np"), d.imageAs("np"))
+    # the library refuses an update that is not the uploaded scene
+    from raytracing_amd import _native
+    from raytracing_amd.flatten import flatten_scene
+    ctx = live._context()
+    T3DE.Light(scene, position=T3DE.Vec3(1, 1, 1))
+    with pytest.raises(_native.NativeError, match="not the uploaded scene"):
+        ctx.update(flatten_scene(scene))
+
+
 def _glass_onion(T3DE):
     """Six nested glass spheres: trace trees that double with every bounce."""
     from raytracing_amd.scene import Camera, Light, Material, Scale, Scene, Shader, Sphere, Vec3, RGB

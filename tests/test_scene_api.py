@@ -238,3 +238,42 @@ def test_stl_reader_ascii_binary_and_cut_off_files(tmp_path):
     odd_file.write_text("\n".join(lines[:-3]) + "\n")                                  # the last facet lost a vertex line
     with pytest.raises(ValueError, match="multiple of three"):
         Mesh.fromSTL(str(odd_file))
+
+
+def test_flatten_cache_bakes_only_what_changed():
+    """flatten_scene with a cache: an unchanged scene gives back the previous result; moved spheres / Lights / camera
+    reuse the triangle arrays ("moved": the device copy can be updated in place); a moved mesh is baked again; a
+    coordinate edited in place is seen by a thorough call; every result equals an uncached flattening."""
+    from raytracing_amd.flatten import FlattenCache, flatten_scene
+    from raytracing_amd.scene import Vec3
+    from raytracing_amd.workloads import cornell_scene
+    scene = cornell_scene(with_light=True, suzanne=True)
+    names = ("tri_verts", "tri_shader", "light_pos", "light_strength", "light_color", "obj_center", "obj_radius", "obj_tri_begin",
+             "obj_tri_count", "shader_color", "shader_rough", "obj_type")
+
+    def same_as_uncached(flat):
+        ref = flatten_scene(scene)
+        return all(np.array_equal(getattr(flat, n), getattr(ref, n)) for n in names) and flat.cam_pos == ref.cam_pos
+
+    cache = FlattenCache()
+    a = flatten_scene(scene, cache, thorough=False)
+    assert cache.change == "full" and same_as_uncached(a)
+    assert flatten_scene(scene, cache, thorough=False) is a and cache.change == "same"
+    assert flatten_scene(scene, cache, thorough=True) is a and cache.change == "same"       # the two kinds of call share the cache
+    light = next(o for o in scene.objects if o.type == "light")
+    light.position = Vec3(0.2, 2.9, 1.1)
+    scene.camera.position = Vec3(0.0, 0.1, -10.0)
+    b = flatten_scene(scene, cache, thorough=False)
+    assert cache.change == "moved" and np.shares_memory(b.tri_verts, a.tri_verts) and same_as_uncached(b) and b.digest() != a.digest()
+    monkey = next(o for o in scene.objects if o.type == "mesh" and len(o.mesh.faces) > 500)
+    monkey.rotation.y += 0.3
+    c = flatten_scene(scene, cache, thorough=False)
+    assert cache.change == "full" and same_as_uncached(c) and not np.shares_memory(c.tri_verts, b.tri_verts)
+    monkey.mesh.vertices[7].x += 0.125                       # not one of the sampled vertices
+    assert flatten_scene(scene, cache, thorough=False) is c  # the quick look does not see it ...
+    d = flatten_scene(scene, cache, thorough=True)           # ... the thorough one does
+    assert cache.change == "full" and d is not c and same_as_uncached(d)
+    assert flatten_scene(scene, cache, thorough=False) is d
+    light.shaders[0].color.r = 13                            # a shader value: not a move
+    e = flatten_scene(scene, cache, thorough=False)
+    assert cache.change == "full" and same_as_uncached(e)

@@ -32,3 +32,19 @@ print(f"t3d_closest_hits through ctypes (one ray): median {np.median(times) * 1e
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable(); photon.render(); pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(12)
+
+# Picking on a LIVE scene (transformBefore False: every query looks at the scene as it is now, explorer.py:324-355) with
+# one Light moved between two queries, on the glass-monkey scene (1018 triangles: traced through the hierarchy)
+import T3DE
+live_scene, live_opt = get_workload("suzanne_4k_b4")
+tracer = T3DR.Photon(live_scene, dict(live_opt, transformBefore=False))
+light = next(o for o in live_scene.objects if o.type == "light")
+ray = tracer.getRay(tracer.pixelToVector(live_opt["width"] // 2, live_opt["height"] // 2))
+tracer.getFirstCollision(ray, True, False)
+for label, move in (("nothing changes between the queries", False), ("one Light moves before every query", True)):
+    times = []
+    for i in range(60):
+        if move:
+            light.position = T3DE.Vec3(0.3 * ((i % 5) - 2), 3.0, 1.0)
+        t = time.perf_counter(); hit = tracer.getFirstCollision(ray, True, False); times.append(time.perf_counter() - t)
+    print(f"picking on the live glass-monkey scene, {label}: median {np.median(times) * 1e6:.1f} us per query (uploads so far {tracer.uploads})")
