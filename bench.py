@@ -341,16 +341,6 @@ def main():
                 lat_run.step(1)
                 sync()
             secondary["frame_latency_s"] = max_over_ranks((time.perf_counter() - t0) / n_lat)
-    # kernel durations (HIP events on the launch stream) come from one more frame, outside the timed region and alone
-    # on the device: events between the launches are stops in the stream, and kernels that share the device with
-    # another frame's have no duration of their own
-    sync()
-    ctx.set_timing(True)
-    torch.cuda.set_stream(streams[0])
-    alone = torch.empty((tile.nrows, W, 3), dtype=torch.uint8, device=device)
-    last = ctx.render_rows_device(options, 0, tile.row0, tile.nrows, alone.data_ptr(), stream=streams[0].cuda_stream,
-                                  want_stats=True, row_stride=tile.stride)
-    sync()
     # the same frame as two bands of rows traced at once by two contexts (t3d_render_rows_device_split): what a caller
     # with ONE frame to render gets; timed by events on the stream the bands are forked from and joined to
     two_bands_ms = None
@@ -361,6 +351,10 @@ def main():
         for c in pair:
             c.set_timing(False)
             c.set_full_rounds(False)
+        torch.cuda.set_stream(streams[0])
+        alone = torch.empty((tile.nrows, W, 3), dtype=torch.uint8, device=device)
+        ctx.render_rows_device(options, 0, tile.row0, tile.nrows, alone.data_ptr(), stream=streams[0].cuda_stream, want_stats=True,
+                               row_stride=tile.stride)
         banded = torch.empty_like(alone)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         times = []
@@ -376,8 +370,16 @@ def main():
         if not torch.equal(banded, alone):
             raise RuntimeError("the frame traced as two bands differs from the frame traced alone")
         two_bands_ms = sorted(times)[len(times) // 2]
-        ctx.set_timing(True)
-        sync()
+    # kernel durations (HIP events on the launch stream) come from one more frame, outside the timed region and alone
+    # on the device: events between the launches are stops in the stream, and kernels that share the device with
+    # another frame's have no duration of their own
+    sync()
+    ctx.set_timing(True)
+    torch.cuda.set_stream(streams[0])
+    alone = torch.empty((tile.nrows, W, 3), dtype=torch.uint8, device=device)
+    last = ctx.render_rows_device(options, 0, tile.row0, tile.nrows, alone.data_ptr(), stream=streams[0].cuda_stream,
+                                  want_stats=True, row_stride=tile.stride)
+    sync()
     whole_alone_ms = None
     if world > 1 and not args.no_secondary:
         # the whole frame on ONE GPU (rank 0's), alone, while the other ranks wait: what the several-rank figures compare with

@@ -11,13 +11,15 @@ cp $G/prof_${tag}_solo/*/*_kernel_stats.csv $P/${r}_bench_solo_kernel_stats.csv
 cp $G/prof_${tag}_bench.json $P/${r}_bench_under_rocprof.json
 cp $G/prof_${tag}_solo_bench.json $P/${r}_bench_solo_under_rocprof.json
 cp $G/${tag}_bench_default.json $P/${r}_bench_default.json
-for w in suzanne_4k_b4 synthetic_200k_1080p_b2 synthetic_1m_4k_b2; do cp $G/${tag}_bench_$w.json $P/${r}_bench_$w.json; done
+for w in suzanne_4k_b4 synthetic_200k_1080p_b2 synthetic_1m_4k_b2 cornell2_8k_b8; do cp $G/${tag}_bench_$w.json $P/${r}_bench_$w.json; done
 cp $G/${tag}_lbvh1m_kernel_trace_summary.txt $P/${r}_lbvh1m_kernel_trace_summary.txt
 cp $G/${tag}_suzanne4k_kernel_trace_summary.txt $P/${r}_suzanne4k_kernel_trace_summary.txt
 cp $G/prof_${tag}_lbvh1m_bench.json $P/${r}_lbvh1m_bench_under_rocprof.json
 cp $G/${tag}_time_api.txt $P/${r}_time_api.txt
 grep -E "^(ranks|   k_level)" $G/${tag}_rank_emulation.txt > $P/${r}_rank_emulation.txt
-for x in "" _lbvh1m; do
+# counter runs: the headline workload under the plain names, the others with a suffix
+for x in "" _lbvh1m _suzanne4k _200k _cornell2_8k; do
+  [ -f "$G/pmc_${pmc}${x}_traffic.json" ] || continue
   python - "$G/pmc_${pmc}${x}_traffic.json" "$P/${r}${x}_pmc_traffic.json" "$commit" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1])); d["commit"] = sys.argv[3]

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 cd /tmp
 pass() {  # name, counters...
   name=$1; shift
-  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_${tag}_$name -- python3 $R/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline --frames-in-flight 1 > /dev/null 2> $R/gpurun_out/pmc_${tag}_$name.err || { echo pass $name failed; tail -5 $R/gpurun_out/pmc_${tag}_$name.err; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_${tag}_$name -- python3 $R/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --frames-in-flight 1 > /dev/null 2> $R/gpurun_out/pmc_${tag}_$name.err || { echo pass $name failed; tail -5 $R/gpurun_out/pmc_${tag}_$name.err; exit 1; }
 }
 pass a SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY &&
 pass b SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SMEM SQ_INSTS_VALU_TRANS_F32 SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM SQ_IFETCH GRBM_GUI_ACTIVE &&

@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 timeout -k 10 300 python -u bench.py > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_bench_default.err || { tail -5 gpurun_out/${tag}_bench_default.err; exit 1; }
 cat gpurun_out/${tag}_bench_default.json
-for w in suzanne_4k_b4 synthetic_200k_1080p_b2 synthetic_1m_4k_b2; do
+for w in suzanne_4k_b4 synthetic_200k_1080p_b2 synthetic_1m_4k_b2 cornell2_8k_b8; do
   timeout -k 10 400 python -u bench.py --workload $w --steps 3 --warmup 1 > gpurun_out/${tag}_bench_$w.json 2> gpurun_out/${tag}_bench_$w.err || { tail -5 gpurun_out/${tag}_bench_$w.err; exit 1; }
   cat gpurun_out/${tag}_bench_$w.json
 done
