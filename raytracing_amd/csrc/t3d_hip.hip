@@ -1807,7 +1807,10 @@ extern "C" int t3d_create(int device, t3d_ctx** out) {
     // working-set budget of one band in MiB (default 48 GiB): small values make small frames take the paths of huge ones
     if (const char* mb = getenv("T3D_MEM_BUDGET_MB")) { const long v = atol(mb); if (v > 0) c->mem_budget = (size_t)v << 20; }
     if (hipMalloc((void**)&c->d_cnt_pair[0], sizeof(Counters)) != hipSuccess || hipMalloc((void**)&c->d_cnt_pair[1], sizeof(Counters)) != hipSuccess ||
-        hipMemset(c->d_cnt_pair[0], 0, sizeof(Counters)) != hipSuccess || hipMemset(c->d_cnt_pair[1], 0, sizeof(Counters)) != hipSuccess ||
+        // (copies and fills go through the context's own stream everywhere in this library: the synchronous forms use the
+        // legacy stream, which HIP refuses while ANOTHER host thread records a launch graph for another context)
+        hipMemsetAsync(c->d_cnt_pair[0], 0, sizeof(Counters), c->stream) != hipSuccess || hipMemsetAsync(c->d_cnt_pair[1], 0, sizeof(Counters), c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess ||
         hipMalloc((void**)&c->d_fetch, sizeof(PaddedCount) * (T3D_MAX_BOUNCES + 2) * 2 * T3D_SHARDS) != hipSuccess ||
         hipHostMalloc((void**)&c->h_cnt, sizeof(Counters), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&c->h_sticky, 64, hipHostMallocDefault) != hipSuccess ||
@@ -1881,7 +1884,10 @@ template <typename T>
 static int upload(t3d_ctx* c, void** dst, const std::vector<T>& v) {
     size_t bytes = sizeof(T) * (v.empty() ? 1 : v.size());
     HIPCHK(c, hipMalloc(dst, bytes));
-    if (!v.empty()) HIPCHK(c, hipMemcpy(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+    if (!v.empty()) {
+        HIPCHK(c, hipMemcpyAsync(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     return T3D_OK;
 }
 
@@ -3321,7 +3327,8 @@ static int trace_single(t3d_ctx* c, const t3d_opts* o, const RenderParams& singl
     if (!rc) {
         n = c->h_cnt->n_dbg < dbg_cap ? c->h_cnt->n_dbg : dbg_cap;
         std::vector<t3d_node> tmp((size_t)(n > 0 ? n : 1));
-        if (n > 0 && hipMemcpy(tmp.data(), d_dbg, sizeof(t3d_node) * n, hipMemcpyDeviceToHost) != hipSuccess) { rc = T3D_E_DEVICE; c->err = "trace: copy of the node records failed"; }
+        if (n > 0 && (hipMemcpyAsync(tmp.data(), d_dbg, sizeof(t3d_node) * n, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                      hipStreamSynchronize(c->stream) != hipSuccess)) { rc = T3D_E_DEVICE; c->err = "trace: copy of the node records failed"; }
         if (!rc) {
             // depth-first order, bounce child (2n) before transmit child (2n+1); heap index -> record
             std::vector<int> where((size_t)worst + 1, -1);

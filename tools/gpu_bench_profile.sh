@@ -16,8 +16,9 @@ cd $R
 if [ $rc -ne 0 ]; then echo "BENCH FAILED rc=$rc"; tail -20 gpurun_out/prof_$tag.err; exit $rc; fi
 echo "== default command (frames in flight: see the bench line) =="
 python tools/prof_summary.py gpurun_out/prof_$tag/*/*_kernel_trace.csv | sed -n '1,/^$/p'
-# one frame at a time: every kernel alone on the device, the launches the roofline figures are about
-cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_solo -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --frames-in-flight 1 > $R/gpurun_out/prof_${tag}_solo_bench.json 2> $R/gpurun_out/prof_${tag}_solo.err
+# one frame at a time and nothing but whole frames (--no-secondary: no half-frame bands, no other seed mode): every kernel alone
+# on the device, the launches the roofline figures are about
+cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_solo -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary --frames-in-flight 1 > $R/gpurun_out/prof_${tag}_solo_bench.json 2> $R/gpurun_out/prof_${tag}_solo.err
 rc=$?
 cd $R
 if [ $rc -ne 0 ]; then echo "BENCH FAILED rc=$rc"; tail -20 gpurun_out/prof_${tag}_solo.err; exit $rc; fi
