@@ -27,6 +27,8 @@ for level in range(opt["bounces"] + 1):
     assert lib.t3d_debug_wave_trace(level, buf.ctypes.data, N) == 0
     used = buf[:, 1] > 0
     b = buf[used]
+    if len(b) == 0:      # one launch per band (k_tree): its waves are recorded as level 0
+        continue
     t0 = b[:, 0].min()
     start = (b[:, 0] - t0).astype(np.float64) / 100.0     # us
     end = (b[:, 1] - t0).astype(np.float64) / 100.0
@@ -57,6 +59,14 @@ for level in range(opt["bounces"] + 1):
         a[0] = min(a[0], s_); a[1] = max(a[1], e_); a[2] += r_
     ends = np.array([v[1] for v in by.values()]); rounds = np.array([v[2] for v in by.values()])
     print(f"    per SIMD: last end us {pct(ends)}; rounds {pct(rounds)}")
+    inp = (b[:, 3] >> np.uint64(40)).astype(int)
+    if inp.any():
+        print(f"    input rounds per wave (min p10 p50 p90 p99 max): {pct(inp)}")
+        gws = np.nonzero(used)[0]
+        sel = (gws % 64) == 5
+        order = np.argsort(end[sel])
+        print("    waves of shard 5 by end time: (end us, input rounds, trace rounds incl. input, shadow rounds, simd key)")
+        print("     ", [(round(float(end[sel][i]), 1), int(inp[sel][i]), int(tr[sel][i]), int(sh[sel][i]), int(key[sel][i])) for i in order])
     late = start > 1.0
     if late.any():
         print(f"    waves that start later than 1 us: {int(late.sum())}, their start {pct(start[late])}")
