@@ -115,7 +115,7 @@ def main():
     ap.add_argument("--accel", default="auto", choices=["auto", "brute", "lbvh"], help="closest-hit structure (auto: by scene size)")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="independent render calls traced at the same time, each with a context and a stream of its own "
-                         "(0: one for LBVH scenes; brute-force scenes three with up to two ranks, four with more)")
+                         "(0: one for LBVH scenes, four for brute-force scenes: as many as the process has hardware queues)")
     ap.add_argument("--frames-per-call", type=int, default=0,
                     help="consecutive frames whose rows one render call traces together, and one gather collects "
                          "(0: as many as there are ranks, so that a call traces a whole frame's worth of rows whatever their number)")
@@ -181,7 +181,8 @@ def main():
     lbvh_scene = args.accel == "lbvh" or (args.accel == "auto" and flat.n_tris + flat.n_spheres > 256)
     # one rank's share of a frame is a chain of small launches: more of them in flight, and full rounds (no slot of a
     # round wasted; the other chains hide the latency the adaptive cut is there to shorten)
-    F = args.frames_in_flight if args.frames_in_flight > 0 else (1 if lbvh_scene else (3 if world <= 2 else 4))
+    # (four: one chain per hardware queue of the process; a fifth shares a queue and costs 9 %, three leave 2.5 % unused)
+    F = args.frames_in_flight if args.frames_in_flight > 0 else (1 if lbvh_scene else 4)
     # One rank's share of a frame shrinks with the number of ranks, and launches that small leave most of a GPU idle:
     # a call traces the rank's rows of B consecutive frames together (t3d_opts.frames) and one gather moves their tiles.
     B = args.frames_per_call if args.frames_per_call > 0 else world

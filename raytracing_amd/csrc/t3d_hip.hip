@@ -1665,6 +1665,7 @@ struct Work {
 struct t3d_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t upload_stream = nullptr;   // exists while t3d_upload_scene runs (UploadStream)
     hipEvent_t ev[(T3D_MAX_BOUNCES + 1) + 4] = {};
     std::string err;
     bool has_scene = false;
@@ -1761,6 +1762,10 @@ struct t3d_ctx {
 };
 
 static thread_local std::string g_create_err;
+// HIP refuses legacy-stream calls of one host thread while another records a launch graph (and the recording is lost):
+// the library's only such call (t3d_create) and its recordings take turns.
+static std::mutex g_capture_mutex;
+static std::once_flag g_legacy_touched[T3D_MAX_DEVICES];
 
 #define HIPCHK(ctx, call)                                                                              \
     do {                                                                                               \
@@ -1807,16 +1812,27 @@ extern "C" int t3d_create(int device, t3d_ctx** out) {
     // working-set budget of one band in MiB (default 48 GiB): small values make small frames take the paths of huge ones
     if (const char* mb = getenv("T3D_MEM_BUDGET_MB")) { const long v = atol(mb); if (v > 0) c->mem_budget = (size_t)v << 20; }
     if (hipMalloc((void**)&c->d_cnt_pair[0], sizeof(Counters)) != hipSuccess || hipMalloc((void**)&c->d_cnt_pair[1], sizeof(Counters)) != hipSuccess ||
-        // (copies and fills go through the context's own stream everywhere in this library: the synchronous forms use the
-        // legacy stream, which HIP refuses while ANOTHER host thread records a launch graph for another context)
-        hipMemsetAsync(c->d_cnt_pair[0], 0, sizeof(Counters), c->stream) != hipSuccess || hipMemsetAsync(c->d_cnt_pair[1], 0, sizeof(Counters), c->stream) != hipSuccess ||
-        hipStreamSynchronize(c->stream) != hipSuccess ||
+        // (copies and fills never go through the legacy stream in this library, see UploadStream)
+        hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMemsetAsync(c->d_cnt_pair[0], 0, sizeof(Counters), c->upload_stream) != hipSuccess ||
+        hipMemsetAsync(c->d_cnt_pair[1], 0, sizeof(Counters), c->upload_stream) != hipSuccess ||
+        hipStreamSynchronize(c->upload_stream) != hipSuccess ||
         hipMalloc((void**)&c->d_fetch, sizeof(PaddedCount) * (T3D_MAX_BOUNCES + 2) * 2 * T3D_SHARDS) != hipSuccess ||
         hipHostMalloc((void**)&c->h_cnt, sizeof(Counters), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&c->h_sticky, 64, hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void**)&c->d_totals, sizeof(CallTotals)) != hipSuccess ||
         hipHostMalloc((void**)&c->h_totals, sizeof(CallTotals), hipHostMallocDefault) != hipSuccess)
         return fail(T3D_E_NOMEM, "counter allocation failed");
+    hipStreamDestroy(c->upload_stream); c->upload_stream = nullptr;
+    // The first context on a device puts one small fill on the device's legacy stream.  HIP gives a stream its place on
+    // one of the process's few hardware queues when it first carries work; with the legacy stream placed first, four
+    // streams of a caller that renders four chains at once end up on queues of their own (one rank's share of an 8-GPU
+    // frame: 0.069 ms per frame, against 0.113 when the first work of the process went through other streams).
+    if (device >= 0 && device < T3D_MAX_DEVICES)
+        std::call_once(g_legacy_touched[device], [&] {
+            std::lock_guard<std::mutex> lk(g_capture_mutex);
+            (void)hipMemset(c->d_cnt_pair[0], 0, 64);
+        });
     if ((e = hipEventCreate(&c->ev_call0)) != hipSuccess) return fail(T3D_E_DEVICE, hipGetErrorString(e));
     if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail(T3D_E_DEVICE, hipGetErrorString(e));
     if ((e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) return fail(T3D_E_DEVICE, hipGetErrorString(e));
@@ -1877,6 +1893,7 @@ extern "C" void t3d_destroy(t3d_ctx* c) {
     if (c->shadow_stream) hipStreamDestroy(c->shadow_stream);
     if (c->capture_stream) hipStreamDestroy(c->capture_stream);
     if (c->stream) hipStreamDestroy(c->stream);
+    if (c->upload_stream) hipStreamDestroy(c->upload_stream);
     delete c;
 }
 
@@ -1885,11 +1902,28 @@ static int upload(t3d_ctx* c, void** dst, const std::vector<T>& v) {
     size_t bytes = sizeof(T) * (v.empty() ? 1 : v.size());
     HIPCHK(c, hipMalloc(dst, bytes));
     if (!v.empty()) {
-        HIPCHK(c, hipMemcpyAsync(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipStream_t st = c->upload_stream ? c->upload_stream : c->stream;
+        HIPCHK(c, hipMemcpyAsync(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st));
     }
     return T3D_OK;
 }
+
+// The copies of an upload go through a stream that exists for the duration of the call.  Not the legacy stream (the
+// synchronous copy functions use it, and HIP refuses them while ANOTHER host thread records a launch graph for another
+// context), and not the context's own stream either: a stream that has carried work keeps its place on one of the
+// process's few hardware queues, and a caller that renders on streams of its own -- four chains on four streams --
+// then shares those queues with the contexts' idle streams (one rank's share of an 8-GPU frame, four calls in flight:
+// 0.113 ms per frame against 0.068).
+struct UploadStream {
+    t3d_ctx* c;
+    explicit UploadStream(t3d_ctx* ctx) : c(ctx) {
+        if (hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->upload_stream = nullptr; }
+    }
+    ~UploadStream() {
+        if (c->upload_stream) { hipStreamSynchronize(c->upload_stream); hipStreamDestroy(c->upload_stream); c->upload_stream = nullptr; }
+    }
+};
 
 // Pieces of the device scene that t3d_upload_scene and t3d_update_scene both make.
 // scene bounds for the camera-ray pre-test, padded outward by 1e-4 of their size (tri_lo / tri_hi: bounds of the triangles)
@@ -1968,6 +2002,7 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_scene(c);
+    UploadStream upload_stream(c);
 
     // Triangles are grouped by supporting plane (same unit normal to 1e-7 and same offset to 1e-6, float64):
     // groups in order of their first triangle, triangles inside a group in their original order.
@@ -2572,6 +2607,7 @@ static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int fra
     static_assert(sizeof(RenderParams) + 12 * sizeof(void*) <= sizeof key, "graph key");
     const bool graphable = c->graphs_enabled && !events && !single && !c->use_bvh && !cancellable && !fixed_work;
     bool capturing = false;
+    std::unique_lock<std::mutex> capture_lock(g_capture_mutex, std::defer_lock);   // held while this thread records
     hipStream_t ls = st;   // where the brute-force path's kernels are queued: the call's stream, or the recording stream
     t3d_ctx::FrameGraph* slot = nullptr;
     // level 0 of the brute-force path: the launch a graph re-parameterises for another seed
@@ -2612,8 +2648,9 @@ static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int fra
                 goto issued;
             }
         if (memcmp(c->graph_miss[0], key, sizeof key) == 0 || memcmp(c->graph_miss[1], key, sizeof key) == 0) {
+            capture_lock.lock();
             if (hipStreamBeginCapture(c->capture_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) { capturing = true; ls = c->capture_stream; }
-            else { (void)hipGetLastError(); c->graphs_enabled = false; }
+            else { (void)hipGetLastError(); c->graphs_enabled = false; capture_lock.unlock(); }
         } else {
             memcpy(c->graph_miss[c->graph_miss_next], key, sizeof key);
             c->graph_miss_next ^= 1;
@@ -2711,6 +2748,7 @@ static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int fra
         c->graph_next = (c->graph_next + 1) % 4;
         if (slot->valid) { hipGraphExecDestroy(slot->exec); hipGraphDestroy(slot->graph); slot->valid = false; }
         hipError_t e = hipStreamEndCapture(c->capture_stream, &slot->graph);
+        capture_lock.unlock();
         if (e == hipSuccess) {
             e = hipGraphInstantiate(&slot->exec, slot->graph, nullptr, nullptr, 0);
             if (e != hipSuccess) hipGraphDestroy(slot->graph);

@@ -53,6 +53,8 @@ for n in ([int(a) for a in args] or [1, 2, 4, 8]):
         ctx.render_rows_device(opt, 0, 0, rows, out.data_ptr(), stream=stream, want_stats=False, row_stride=n, frames=B)
     torch.cuda.synchronize()
     chains = [(ctx, stream, out)] + [(c, s.cuda_stream, torch.empty_like(out)) for c, s in zip(more, more_streams)]
+    if os.environ.get("RANK_EMU_OWN_STREAMS"):   # every chain on its context's own stream instead of a stream of the caller's
+        chains = [(c, 0, o) for c, _, o in chains]
     K = 200 if workload == "cornell_1080p_b4" else 6
     tstreams = [torch_stream] + more_streams
     recv = [torch.empty_like(out) for _ in range(F)]
