@@ -689,7 +689,7 @@ def test_bench_gather_in_a_one_rank_rccl_group():
     and its watchdog thread included, on a one-GPU box.  bench.py checks the gathered frames against the tiles."""
     d = _run_bench_ranks(1, ["--one-rank-group", "--no-cpu-baseline"], steps=24, warmup=2)
     assert d["n_gpus"] == 1 and d["config"]["collective"] == "RCCL gather in a group of one rank"
-    assert d["config"]["calls_in_flight"] == 3 and d["scaling"] == "strong"
+    assert d["config"]["calls_in_flight"] == 4 and d["scaling"] == "strong"
     _check_frame_counts(d)
 
 

@@ -16,8 +16,7 @@ timeout -k 10 200 python -u tools/time_api.py > gpurun_out/${tag}_time_api.txt 2
 cat gpurun_out/${tag}_time_api.txt
 # one frame per call, then as bench.py runs several ranks: as many frames per call as there are ranks
 timeout -k 10 200 python -u tools/rank_emulation.py f4 g 1 2 4 8 > gpurun_out/${tag}_rank_emulation.txt 2>&1 || { tail -5 gpurun_out/${tag}_rank_emulation.txt; exit 1; }
-timeout -k 10 200 python -u tools/rank_emulation.py f3 bw g 2 >> gpurun_out/${tag}_rank_emulation.txt 2>&1 || { tail -5 gpurun_out/${tag}_rank_emulation.txt; exit 1; }
-timeout -k 10 200 python -u tools/rank_emulation.py f4 bw g 4 8 >> gpurun_out/${tag}_rank_emulation.txt 2>&1 || { tail -5 gpurun_out/${tag}_rank_emulation.txt; exit 1; }
+timeout -k 10 200 python -u tools/rank_emulation.py f4 bw g 2 4 8 >> gpurun_out/${tag}_rank_emulation.txt 2>&1 || { tail -5 gpurun_out/${tag}_rank_emulation.txt; exit 1; }
 for w in suzanne_4k_b4 synthetic_1m_4k_b2; do
   timeout -k 10 300 python -u tools/rank_emulation.py $w f1 1 8 >> gpurun_out/${tag}_rank_emulation.txt 2>&1 || { tail -5 gpurun_out/${tag}_rank_emulation.txt; exit 1; }
   timeout -k 10 300 python -u tools/rank_emulation.py $w f1 bw 2 4 8 >> gpurun_out/${tag}_rank_emulation.txt 2>&1 || { tail -5 gpurun_out/${tag}_rank_emulation.txt; exit 1; }
