@@ -189,7 +189,6 @@ struct alignas(64) PaddedCount {
 struct Counters {
     PaddedCount n_rays[T3D_MAX_BOUNCES + 2][T3D_SHARDS];   // rays queued for each level, per shard
     PaddedCount n_nodes[T3D_MAX_BOUNCES + 2][T3D_SHARDS];  // shaded nodes of each level, per shard
-    PaddedCount n_pairs[T3D_MAX_BOUNCES + 2][T3D_SHARDS];  // (node, light) pairs queued for k_shadow, per level and shard
     int overflow;
     int n_dbg;
     int bvh_stack_overflow;
@@ -928,7 +927,6 @@ struct PairList {
     unsigned short* ring;   // T3D_PAIRS entries in LDS: slot | light << 8
     int tail;               // pairs appended so far (wave-uniform)
     uint32_t culled;        // pairs answered without a ray, this lane
-    int* gq = nullptr;      // k_trace: this level's pair queue in global memory, node << 3 | light, shard after shard
 };
 
 // Everything that follows the closest hits of the NR rays of a lane (wave-collective: ballots and atomics):
@@ -1008,7 +1006,7 @@ __device__ __forceinline__ void process_rays(const DevScene& sc, const DevLight*
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         live[r] = 0; pair_pos[r] = 0;
-        if constexpr (PAIRS) {
+        if constexpr (RING > 0 && PAIRS) {
             const V3 V = mk(sc.cam.pos[0] - oc[r].P.x, sc.cam.pos[1] - oc[r].P.y, sc.cam.pos[2] - oc[r].P.z);
             const float vv = dot(V, V);
             pair_pos[r] = pairs_total;
@@ -1022,12 +1020,6 @@ __device__ __forceinline__ void process_rays(const DevScene& sc, const DevLight*
                 live[r] |= (uint32_t)lv << l;
             }
         }
-    }
-    // k_trace (PAIRS without a ring): the listed pairs go to the level's queue in global memory; the answer to this
-    // reservation is needed last, after the node records and the child rays
-    int base_p = 0;
-    if constexpr (RING == 0 && PAIRS) {
-        if (wc.lane == 0 && pairs_total) base_p = atomicAdd(&cnt->n_pairs[wc.level][wc.shard].v, pairs_total);
     }
     base_n = __shfl(base_n, 0);
     base_r = __shfl(base_r, 0);
@@ -1073,28 +1065,11 @@ __device__ __forceinline__ void process_rays(const DevScene& sc, const DevLight*
             } else { cnt->overflow = 1; rp.sticky[0] = 1; }
         }
     }
-    if constexpr (RING == 0 && PAIRS) base_p = __shfl(base_p, 0);
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const V3 P = oc[r].P, N = oc[r].N;
         const float rough = oc[r].rough;
-        if constexpr (RING == 0 && PAIRS) {
-            // shading inputs by the node's position in its level, pairs to the shard's queue.  A node that found no room
-            // (the band is traced again with more) still fills its reserved queue entries, with node 0.
-            if (live[r]) {
-                const int nd = stored[r] ? node[r] : 0;
-                if (stored[r]) {
-                    ring_a[nd] = make_float4(P.x, P.y, P.z, rough);
-                    ring_b[nd] = make_float4(N.x, N.y, N.z, 0.0f);
-                }
-                const int pos = base_p + pair_pos[r], qcap = wc.shard_cap * wc.L;
-                for (int l = 0; l < wc.L; ++l) {
-                    const int ploc = pos + __popc(live[r] & ((1u << l) - 1u));
-                    if (((live[r] >> l) & 1u) && ploc < qcap) pl->gq[(size_t)wc.shard * qcap + ploc] = (nd << 3) | l;
-                }
-            }
-            if (oc[r].shaded) pl->culled += (uint32_t)(wc.L - __popc(live[r]));
-        } else if constexpr (RING > 0 && PAIRS) {
+        if constexpr (RING > 0 && PAIRS) {
             // only nodes with a listed pair enter the ring
             const unsigned long long m_r = __ballot(live[r] != 0);
             if (live[r]) {
@@ -1334,93 +1309,6 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_level(DevScene sc, GEO_PARAMS
         unsigned long long f = pl.culled;
         for (int off = 32; off > 0; off >>= 1) f += __shfl_xor(f, off);
         if (wc.lane == 0 && f) atomicAdd(&cnt->bvh_stat[wc.shard][4], f);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// A level as two launches (brute-force path, scenes with few lights): k_trace runs the level's trace rounds and leaves
-// the (node, light) pairs worth a shadow ray in a queue in global memory, k_shadow runs the shadow rounds from that queue.
-// The same rounds as k_level's, but a shadow round is no longer tied to the wave that created its nodes: every round
-// of k_shadow is full, its waves carry nothing of the classification and fit more to a SIMD, and the shadow rays of
-// level d may run beside the trace rounds of level d + 1.
-// ------------------------------------------------------------------------------------------------
-#ifndef T3D_TRACE_WAVES
-#define T3D_TRACE_WAVES 5   // waves per SIMD k_trace is compiled for below level 0
-#endif
-template <bool LEVEL0>
-__global__ __launch_bounds__(64, LEVEL0 ? 4 : T3D_TRACE_WAVES) void k_trace(DevScene sc, GEO_PARAMS, const DevLight* __restrict__ light_rows, RenderParams rp, int level,
-                                                 const RayRec* __restrict__ rays_in, RayRec* __restrict__ rays_out, NodePool pool,
-                                                 Counters* cnt, TraceOut out, float4* __restrict__ src_a, float4* __restrict__ src_b,
-                                                 int* __restrict__ pair_q) {
-    WaveCtx wc;
-    wc.lane = threadIdx.x & 63; wc.wid = 0;
-    wc.lt_mask = (1ull << wc.lane) - 1ull;
-    const int gw = blockIdx.x, nw = gridDim.x;   // one wave per workgroup; the grid holds a multiple of T3D_SHARDS
-    wc.shard = gw & ((1 << rp.shard_bits) - 1);
-    wc.shard_cap = rp.cap >> rp.shard_bits;
-    wc.level = level;
-    wc.node_base = (size_t)level * rp.cap;
-    wc.L = sc.n_lights;
-    const int n_in = LEVEL0 ? rp.n0 : min(cnt->n_rays[level][wc.shard].v, wc.shard_cap);
-    const int queue_base = wc.shard * wc.shard_cap;
-    const int chunk_step = LEVEL0 ? nw : nw >> rp.shard_bits;
-    const int resident_all = nw < rp.resident_waves ? nw : rp.resident_waves;
-    const int resident = LEVEL0 ? resident_all : resident_all >> rp.shard_bits;
-    const int cs = rp.full_rounds || n_in > 64 * resident ? 128 : (n_in > 32 * resident ? 64 : 32);   // see k_level
-    int unused = 0;
-    PairList pl{nullptr, 0, 0u, pair_q};
-    for (int chunk = LEVEL0 ? gw : gw >> rp.shard_bits; (long long)chunk * cs < n_in; chunk += chunk_step) {
-        RayIn in[2];
-        load_ray<LEVEL0, false>(sc, rp, rays_in, chunk * cs + wc.lane, wc.lane < cs ? n_in : 0, queue_base, in[0]);
-        load_ray<LEVEL0, false>(sc, rp, rays_in, chunk * cs + 64 + wc.lane, cs == 128 ? n_in : 0, queue_base, in[1]);
-        const bool lights = LEVEL0 ? (rp.lights != 0) : true;
-        Hit h[2];  // back faces culled iff ray.ior == 1 (T3DR.py:961)
-        closest_hit2<LEVEL0>(GEO_ARGS, sc.geo, in[0].o, in[0].d, in[1].o, in[1].d, lights, in[0].ior == 1.0f, in[1].ior == 1.0f, h[0], h[1]);
-        process_rays<LEVEL0, 0, true, false, 2>(sc, light_rows, rp, wc, in, h, rays_out, pool, cnt, out, src_a, src_b, unused, &pl);
-    }
-    unsigned long long f = pl.culled;
-    for (int off = 32; off > 0; off >>= 1) f += __shfl_xor(f, off);
-    if (wc.lane == 0 && f) atomicAdd(&cnt->bvh_stat[wc.shard][4], f);
-}
-
-#ifndef T3D_SHADOW_WAVES
-#define T3D_SHADOW_WAVES 6   // waves per SIMD k_shadow is compiled for
-#endif
-__global__ __launch_bounds__(64, T3D_SHADOW_WAVES) void k_shadow(DevScene sc, GEO_PARAMS, const DevLight* __restrict__ light_rows, RenderParams rp,
-                                                                  int level, const float4* __restrict__ src_a, const float4* __restrict__ src_b,
-                                                                  const int* __restrict__ pair_q, float* __restrict__ li,
-                                                                  const Counters* __restrict__ cnt) {
-    const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x, nw = gridDim.x;
-    const int shard = gw & ((1 << rp.shard_bits) - 1);
-    const int shard_cap = rp.cap >> rp.shard_bits;
-    const int L = sc.n_lights;
-    const int qcap = shard_cap * L;
-    const int n = min(cnt->n_pairs[level][shard].v, qcap);
-    const int* __restrict__ q = pair_q + (size_t)shard * qcap;
-    const size_t node_base = (size_t)level * rp.cap;
-    for (int chunk = gw >> rp.shard_bits; (long long)chunk * 128 < n; chunk += nw >> rp.shard_bits) {
-        // pairs chunk * 128 + lane and + 64 + lane; a lane without a pair of its own repeats the round's first one and stores nothing
-        const int first = chunk * 128, item0 = first + lane, item1 = item0 + 64;
-        const bool run0 = item0 < n, run1 = item1 < n;
-        const int e0 = q[run0 ? item0 : first], e1 = q[run1 ? item1 : first];
-        // whatever an entry holds (a band that overflowed is traced again), node and light stay inside the arrays
-        const int nd0 = min(max(e0 >> 3, 0), rp.cap - 1), nd1 = min(max(e1 >> 3, 0), rp.cap - 1);
-        const int l0 = min(e0 & 7, L - 1), l1 = min(e1 & 7, L - 1);
-        const ShadowRay s0 = shadow_ray(light_rows[l0], src_a[nd0], src_b[nd0]);
-        const ShadowRay s1 = shadow_ray(light_rows[l1], src_a[nd1], src_b[nd1]);
-        // bounded just behind the light first, then (wave-uniform, rare) without a bound: see k_level
-        Hit h0, h1;
-        closest_hit2<false, true>(GEO_ARGS, sc.geo, s0.start, s0.Ld, s1.start, s1.Ld, true, false, false, h0, h1, nullptr, s0.reach, s1.reach);
-        if (__any((int)(h0.prim < 0) | (int)(h1.prim < 0))) {
-            Hit g0, g1;
-            closest_hit2<false, true>(GEO_ARGS, sc.geo, s0.start, s0.Ld, s1.start, s1.Ld, true, false, false, g0, g1);
-            if (h0.prim < 0) h0 = g0;
-            if (h1.prim < 0) h1 = g1;
-        }
-        const float I0 = shadow_intensity(sc, spheres, s0, h0), I1 = shadow_intensity(sc, spheres, s1, h1);
-        if (run0) li[(node_base + (size_t)nd0) * L + l0] = I0;
-        if (run1) li[(node_base + (size_t)nd1) * L + l1] = I1;
     }
 }
 
@@ -1769,7 +1657,6 @@ struct Work {
     // LBVH path only: closest hit of every ray of the current level; shading inputs of its new nodes
     uint2* hits = nullptr;
     float4* src_a[2] = {nullptr, nullptr}; float4* src_b[2] = {nullptr, nullptr};  // by level parity: see render_band
-    int* pair_q[2] = {nullptr, nullptr};   // split brute-force path: the (node, light) pairs k_trace leaves for k_shadow, by level parity
     size_t n0 = 0;       // primary samples sample_color holds
     float4* sample_color = nullptr;
     uint64_t gen = 0;    // counts (re)allocations: a launch graph holds the addresses
@@ -1845,7 +1732,6 @@ struct t3d_ctx {
     int graph_miss_next = 0;
     bool graphs_enabled = true;
     bool full_rounds = false;       // t3d_set_rounds
-    int split = 0;                  // brute-force levels as k_trace + k_shadow: 1 on one stream, 2 shadow rays beside the next level
     uint64_t scene_gen = 0;         // counts uploads
     // Overflow that nobody was waiting for.  An asynchronous render call (no stats) returns before its kernels have run, so
     // a trace tree that outgrows the queues or node arrays cannot be reported by that call.  The kernels raise these two
@@ -1923,7 +1809,6 @@ extern "C" int t3d_create(int device, t3d_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_sm = prop.multiProcessorCount;
     if (getenv("T3D_NO_GRAPHS")) c->graphs_enabled = false;
-    if (const char* sp = getenv("T3D_SPLIT")) c->split = atoi(sp);
     // working-set budget of one band in MiB (default 48 GiB): small values make small frames take the paths of huge ones
     if (const char* mb = getenv("T3D_MEM_BUDGET_MB")) { const long v = atol(mb); if (v > 0) c->mem_budget = (size_t)v << 20; }
     if (hipMalloc((void**)&c->d_cnt_pair[0], sizeof(Counters)) != hipSuccess || hipMalloc((void**)&c->d_cnt_pair[1], sizeof(Counters)) != hipSuccess ||
@@ -1977,7 +1862,7 @@ static void free_work(Work& w) {
     hipFree(w.rays[0]); hipFree(w.rays[1]); hipFree(w.pool.parent); hipFree(w.pool.c);
     hipFree(w.pool.d); hipFree(w.pool.dbg); hipFree(w.pool.li);
     hipFree(w.hits);
-    for (int k = 0; k < 2; ++k) { hipFree(w.src_a[k]); hipFree(w.src_b[k]); hipFree(w.pair_q[k]); }
+    for (int k = 0; k < 2; ++k) { hipFree(w.src_a[k]); hipFree(w.src_b[k]); }
     hipFree(w.sample_color);
     w = Work{};
     w.gen = gen;
@@ -2508,9 +2393,7 @@ extern "C" int t3d_update_scene(t3d_ctx* c, const t3d_scene_desc* s) {
 }
 
 static int ensure_work(t3d_ctx* c, Work& w, size_t cap, int levels, size_t n0, bool dbg) {
-    const bool split = c->split && !c->use_bvh && &w == &c->work;
-    if (cap > w.cap || levels > w.levels || (dbg && !w.pool.dbg) || c->sc.n_lights > w.li_lights || (c->use_bvh && !w.hits) ||
-        (split && !w.pair_q[0])) {
+    if (cap > w.cap || levels > w.levels || (dbg && !w.pool.dbg) || c->sc.n_lights > w.li_lights || (c->use_bvh && !w.hits)) {
         const size_t keep_n0 = w.n0;
         float4* keep_color = w.sample_color;
         w.sample_color = nullptr;
@@ -2528,13 +2411,6 @@ static int ensure_work(t3d_ctx* c, Work& w, size_t cap, int levels, size_t n0, b
             for (int k = 0; k < 2; ++k) {
                 HIPCHK(c, hipMalloc((void**)&w.src_a[k], sizeof(float4) * cap2));
                 HIPCHK(c, hipMalloc((void**)&w.src_b[k], sizeof(float4) * cap2));
-            }
-        }
-        if (split) {
-            for (int k = 0; k < 2; ++k) {
-                HIPCHK(c, hipMalloc((void**)&w.src_a[k], sizeof(float4) * cap2));
-                HIPCHK(c, hipMalloc((void**)&w.src_b[k], sizeof(float4) * cap2));
-                HIPCHK(c, hipMalloc((void**)&w.pair_q[k], sizeof(int) * cap2 * (size_t)(c->sc.n_lights > 0 ? c->sc.n_lights : 1)));
             }
         }
         HIPCHK(c, hipMalloc((void**)&w.pool.li, sizeof(float) * cap2 * lv * (size_t)(c->sc.n_lights > 0 ? c->sc.n_lights : 1)));
@@ -2673,9 +2549,6 @@ static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int fra
     const bool pairs = !c->use_bvh && c->sc.n_lights >= 1 && c->sc.n_lights <= T3D_PAIR_LIGHTS && c->sc.n_shaders < (1 << T3D_LIVE_SHIFT);
     rp.live_masks = pairs;
     rp.sticky = c->h_sticky;
-    // the brute-force levels as two launches each (k_trace, k_shadow): image bands of scenes with a pair list, node numbers of 28 bits
-    const bool split = c->split && pairs && !single && w.pair_q[0] && cap < ((size_t)1 << 28);
-    if (split) rp.resident_waves = c->n_sm * 4 * T3D_TRACE_WAVES;
     if (single) {
         rp.single = single->single; rp.px0 = single->px0; rp.py0 = single->py0; rp.sample0 = single->sample0; rp.want_debug = 1;
         for (int k = 0; k < 3; ++k) { rp.ray_o[k] = single->ray_o[k]; rp.ray_d[k] = single->ray_d[k]; }
@@ -2755,11 +2628,9 @@ static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int fra
             if (g.valid && memcmp(g.key, key, sizeof key) == 0 && (g.seed == rp.seed || g.level0)) {
                 if (g.seed != rp.seed) {
                     // another frame of the same band: the level-0 node gets this call's parameters (only the seed differs)
-                    level0_fn = split ? (void*)k_trace<true> : pairs ? (void*)k_level<true, 1, true> : (void*)k_level<true, 1, false>;
-                    // (k_trace takes three more arguments; k_level ignores the tail of the list)
+                    level0_fn = pairs ? (void*)k_level<true, 1, true> : (void*)k_level<true, 1, false>;
                     void* kargs[] = {(void*)&c->sc, (void*)&planes, (void*)&pfirst, (void*)&uv, (void*)&sph, (void*)&c->sc.lights, (void*)&rp,
-                                     (void*)&level0_depth, (void*)&level0_in, (void*)&level0_out, (void*)&w.pool, (void*)&c->d_cnt, (void*)&out,
-                                     (void*)&w.src_a[0], (void*)&w.src_b[0], (void*)&w.pair_q[0]};
+                                     (void*)&level0_depth, (void*)&level0_in, (void*)&level0_out, (void*)&w.pool, (void*)&c->d_cnt, (void*)&out};
                     hipKernelNodeParams np{};
                     np.func = level0_fn; np.gridDim = dim3(level0_grid); np.blockDim = dim3(64); np.sharedMemBytes = 0;
                     np.kernelParams = kargs; np.extra = nullptr;
@@ -2834,29 +2705,7 @@ static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int fra
             // 75 % of the resident count is slower alone, 200 % and more lose the overlap).
             const int grid_0 = grid_n * T3D_WAVES;
             const int grid_w = std::min(grid_0, (rp.resident_waves + T3D_SHARDS - 1) / T3D_SHARDS * T3D_SHARDS);
-            if (split) {
-                float4* src_a = w.src_a[d & 1];
-                float4* src_b = w.src_b[d & 1];
-                int* pq = w.pair_q[d & 1];
-                const bool fork = c->split >= 2;
-                // the classification of level d overwrites the shading inputs and the queue that the shadow rays of level d - 2 read
-                if (fork && d >= 2) HIPCHK(c, hipStreamWaitEvent(ls, c->ev_shadowed[d - 2], 0));
-                if (d == 0) hipLaunchKernelGGL(k_trace<true>, dim3(grid_0), dim3(64), 0, ls, c->sc, planes, pfirst, uv, sph, c->sc.lights, rp, d, in, outq,
-                                               w.pool, c->d_cnt, out, src_a, src_b, pq);
-                else hipLaunchKernelGGL(k_trace<false>, dim3(grid_w), dim3(64), 0, ls, c->sc, planes, pfirst, uv, sph, c->sc.lights, rp, d, in, outq,
-                                        w.pool, c->d_cnt, out, src_a, src_b, pq);
-                hipStream_t ss = ls;
-                if (fork) {
-                    ss = c->shadow_stream;
-                    HIPCHK(c, hipEventRecord(c->ev_traced[d], ls));
-                    HIPCHK(c, hipStreamWaitEvent(ss, c->ev_traced[d], 0));
-                }
-                const int grid_s = (c->n_sm * 4 * T3D_SHADOW_WAVES + T3D_SHARDS - 1) / T3D_SHARDS * T3D_SHARDS;
-                hipLaunchKernelGGL(k_shadow, dim3(grid_s), dim3(64), 0, ss, c->sc, planes, pfirst, uv, sph, c->sc.lights, rp, d,
-                                   (const float4*)src_a, (const float4*)src_b, (const int*)pq, w.pool.li, (const Counters*)c->d_cnt);
-                if (fork) HIPCHK(c, hipEventRecord(c->ev_shadowed[d], ss));
-                launches += 1;
-            } else if (!single) {
+            if (!single) {
                 if (d == 0) { if (pairs) T3D_LAUNCH_LEVEL(true, 1, true, grid_0, 64); else T3D_LAUNCH_LEVEL(true, 1, false, grid_0, 64); }
                 else        { if (pairs) T3D_LAUNCH_LEVEL(false, 1, true, grid_w, 64); else T3D_LAUNCH_LEVEL(false, 1, false, grid_w, 64); }
             } else {
@@ -2881,8 +2730,6 @@ static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int fra
     }
     if (overlap && c->sc.n_lights > 0)   // the resolve reads every level's light intensities
         for (int d = levels >= 2 ? levels - 2 : 0; d < levels; ++d) HIPCHK(c, hipStreamWaitEvent(st, c->ev_shadowed[d], 0));
-    if (split && c->split >= 2)
-        for (int d = levels >= 2 ? levels - 2 : 0; d < levels; ++d) HIPCHK(c, hipStreamWaitEvent(ls, c->ev_shadowed[d], 0));
     for (int d = levels - 1; d >= 0; --d) {
         // eight workgroups per CU at most: a grid twice that size is no faster for these short, memory-bound launches
         int rgrid = trace_blocks_for(cap_used);
@@ -2922,7 +2769,7 @@ static int render_band(t3d_ctx* c, Work& w, const t3d_opts* o, int row0, int fra
             hipGraphNode_t root = nullptr;
             hipGraphNodeType ty;
             hipKernelNodeParams np{};
-            const void* want = split ? (const void*)k_trace<true> : pairs ? (const void*)k_level<true, 1, true> : (const void*)k_level<true, 1, false>;
+            const void* want = pairs ? (const void*)k_level<true, 1, true> : (const void*)k_level<true, 1, false>;
             if (hipGraphGetRootNodes(slot->graph, nullptr, &n_root) == hipSuccess && n_root == 1 &&
                 hipGraphGetRootNodes(slot->graph, &root, &n_root) == hipSuccess && hipGraphNodeGetType(root, &ty) == hipSuccess &&
                 ty == hipGraphNodeTypeKernel && hipGraphKernelNodeGetParams(root, &np) == hipSuccess && np.func == want &&
