@@ -105,7 +105,7 @@ struct DevCamera {
 #define GEO_ARGS planes, plane_first, tri_uv, spheres
 
 struct DevGeo {
-    int axis_end[3];  // classes of plane groups [0, axis_end[0]) have their largest normal component along x, then y, then z
+    int axis_end[3];  // plane groups [0, axis_end[0]) have their largest normal component along x, then y, then z
     int n_tris, n_spheres;
     float box_lo[3], box_hi[3];  // bounds of every triangle and sphere, padded outward
 };
@@ -290,122 +290,84 @@ __device__ __forceinline__ f2 step01(f2 m, f2 big) {
     return r;
 }
 
-// Plane groups whose normal is largest along axis AX (getFaceCollision, T3DR.py:624-651), visited CLASS by class: a class
-// is up to eight groups whose planes are parallel (walls and their back faces, floor / ceiling / box tops, the opposite
-// sides of a box), so everything that depends on the plane's direction only is worked out once per class:
-//     d.n^, n^.o (n^: the unit normal of the class),  ok = step01((d.n^)^2 - thr^2),  inv = 1 / (d.n^ * ok)
-// (thr = 1e-6 / |n| of the class's first triangle: the reference rejects |d.n| < 1e-6 on the un-normalised normal;
-// rejected rays divide by zero: every t of the class is +-inf or NaN), and a plane of the class costs one add, one
-// multiply and two compares:
-//     t = -(n^.o + off) * inv        off: the plane's offset along n^
-// A group faces along n^ or against it; where back faces are culled (every lane outside the masks nocull0 / nocull1) a ray meets the former only
-// with d.n^ < 0 and the latter only with d.n^ > 0.  Distances are compared as UNSIGNED integer bit patterns:
-// bits(t) < bits(best) holds exactly for 0 <= t < best and fails for negative, infinite and NaN values, so neither
-// "t >= 0" nor the rejections need a test of their own.  The planes of a class are first tested against the best
-// distances the rays had when the class began (straight-line code, the offsets sit in the class record); only groups
-// that some ray of the wave can still improve on are entered, each with one 64-byte request for its record.
-// Per triangle of an entered group, in the two coordinates (s, t) that remain after dropping axis AX:
+// Plane groups whose normal is largest along axis AX (getFaceCollision, T3DR.py:624-651).
+// Per group:  d.n,  q = n.o - n.v0,  and the plane-level rejections folded into the divisor:
+//     ok = step01(min((d.n)^2 - 1e-12, cull - d.n))      |d.n| > 1e-6 and (d.n < 0 or both sides count)
+//     t  = -q / (d.n * ok)                               rejected planes divide by zero: t = +-inf or NaN
+// (cull = 0 when back faces are rejected, +inf otherwise; packed instructions have no |x| modifier, hence the
+// square).  Distances are compared as UNSIGNED integer bit patterns: bits(t) < bits(best) holds exactly for
+// 0 <= t < best and fails for negative, infinite and NaN values, so neither "t >= 0" nor the rejections need a
+// test of their own.  A group whose plane cannot beat the current best of any lane is skipped by the whole wave.
+// Per triangle of the group, in the two coordinates (s, t) that remain after dropping axis AX:
 //     u = a.(Ps, Pt) + aw,  v = b.(Ps, Pt) + bw,  w = 1 - u - v;   inside <=> min3(u, v, w) > 0 (strict: edges miss)
 // The hit flags of a group (at most 24 triangles) are collected as the bits of an integer kept in a float:
 //     A = 2 A + step01(min3(u, v, w))
 // so its highest set bit is the FIRST triangle hit, which is the one the reference keeps (T3DR.py:715).
-// Records (t3d_upload_scene):
-//   class  4 rows: (n^.x, n^.y, n^.z, -thr^2), (row of its first group's record, number of its first group, count, bit j: group j
-//                  faces against n^), offsets of groups 0..3, offsets of groups 4..7 (NaN where there is none)
-//   group  4 rows: (off, first triangle, end of its triangle range, 1: its first two triangles form a parallelogram), then
-//                  the barycentric rows of its first two triangles as 6 + 6 values: a_s, aw, b_s, bw, a_t, b_t
 template <int AX, bool NO_CULL>
 __device__ __forceinline__ void plane_groups(const float4* __restrict__ planes, const int* __restrict__ plane_first,
-                                             const float4* __restrict__ tri_uv, int c_begin, int c_end, f2 ox, f2 oy, f2 oz,
-                                             f2 dx, f2 dy, f2 dz, unsigned long long nocull0, unsigned long long nocull1, f2 big, uint32_t& best0, uint32_t& best1, float& A0,
+                                             const float4* __restrict__ tri_uv, int g_begin, int g_end, f2 ox, f2 oy, f2 oz,
+                                             f2 dx, f2 dy, f2 dz, f2 cull, f2 big, uint32_t& best0, uint32_t& best1, float& A0,
                                              float& A1, int& bg0, int& bg1, GroupCount* gc = nullptr) {
     const f2 os = AX == 0 ? oy : (AX == 1 ? oz : ox), ot = AX == 0 ? oz : (AX == 1 ? ox : oy);
     const f2 ds = AX == 0 ? dy : (AX == 1 ? dz : dx), dt = AX == 0 ? dz : (AX == 1 ? dx : dy);
-    for (int c = c_begin; c < c_end; ++c) {
-        const float4 cn = planes[4 * c], ck = planes[4 * c + 1], co0 = planes[4 * c + 2], co1 = planes[4 * c + 3];
-        asm volatile("" :: "s"(cn.x), "s"(ck.x), "s"(co0.x), "s"(co1.w));   // the whole class record in one request
-        const f2 dn = fma2(splat(cn.z), dz, fma2(splat(cn.y), dy, splat(cn.x) * dx));
-        const f2 no = fma2(splat(cn.z), oz, fma2(splat(cn.y), oy, splat(cn.x) * ox));
-        const f2 dnv = dn * step01(fma2(dn, dn, splat(cn.w)), big);
+    for (int g = g_begin; g < g_end; ++g) {
+        // One 96-byte record per group: plane row, triangle range, and the rows of its first two triangles --
+        // requested together, so a group of up to two triangles costs a single wait on scalar memory.
+        const float4 rn = planes[6 * g], rk = planes[6 * g + 1];
+        const float4 fa0 = planes[6 * g + 2], fb0 = planes[6 * g + 3], fa1 = planes[6 * g + 4], fb1 = planes[6 * g + 5];
+        const f2 dn = fma2(splat(rn.w), dz, fma2(splat(rn.z), dy, splat(rn.x) * dx));
+        const f2 q = fma2(splat(rn.w), oz, fma2(splat(rn.z), oy, fma2(splat(rn.x), ox, splat(rn.y))));  // n.o - n.v0
+        const f2 e = fma2(dn, dn, splat(-1e-12f));
+        f2 mn = e;
+        if constexpr (!NO_CULL) {   // shadow rays count both sides of every face: no cull term for them
+            const f2 c = cull - dn;
+            mn = f2{fminf(e.x, c.x), fminf(e.y, c.y)};
+        }
+        const f2 dnv = dn * step01(mn, big);
         const f2 inv = {__builtin_amdgcn_rcpf(dnv.x), __builtin_amdgcn_rcpf(dnv.y)};
-        // which rays may meet a group that faces along n^ (p) / against it (m): all of them unless back faces are culled
-        // (kept as lane masks in scalar registers: choosing between them per group is scalar work)
-        unsigned long long fp0 = ~0ull, fp1 = ~0ull, fm0 = ~0ull, fm1 = ~0ull;
-        if constexpr (!NO_CULL) {
-            fp0 = __builtin_amdgcn_ballot_w64(dn.x < 0.0f) | nocull0; fm0 = __builtin_amdgcn_ballot_w64(dn.x > 0.0f) | nocull0;
-            fp1 = __builtin_amdgcn_ballot_w64(dn.y < 0.0f) | nocull1; fm1 = __builtin_amdgcn_ballot_w64(dn.y > 0.0f) | nocull1;
+        const f2 t = -q * inv;
+        const uint32_t tp0 = __float_as_uint(t.x), tp1 = __float_as_uint(t.y);
+        // four of five groups are entered: their range and first rows are asked for together with the plane row (this empty
+        // statement needs them, so the requests stay in front of the branch)
+        asm volatile("" :: "s"(rk.w), "s"(fa0.w), "s"(fb0.w));
+        GC_ADD(gc, visited, 1);
+        if (!__any((tp0 < best0) | (tp1 < best1))) continue;  // wave-uniform
+        GC_ADD(gc, entered, 1);
+        GC_ADD(gc, steps, (__float_as_int(rk.y) - __float_as_int(rk.x) + 1) / 2);
+        const int k0 = __float_as_int(rk.x), k1 = __float_as_int(rk.y);
+        const f2 ps = fma2(ds, t, os), pt = fma2(dt, t, ot);
+        auto inside = [&](float4 ra, float4 rb) -> f2 {
+            const f2 u = fma2(splat(ra.z), pt, fma2(splat(ra.x), ps, splat(ra.y)));
+            const f2 v = fma2(splat(rb.z), pt, fma2(splat(rb.x), ps, splat(rb.y)));
+            const f2 w = (splat(1.0f) - u) - v;
+            const f2 m = {fminf(fminf(u.x, v.x), w.x), fminf(fminf(u.y, v.y), w.y)};
+            return step01(m, big);
+        };
+        // two triangles per step; the first step always covers two bit positions (a group of one triangle has
+        // an all-zero second row pair, which is never inside)
+        f2 A;
+        if (__float_as_int(rk.z) != 0) {   // wave-uniform: the first two triangles form a parallelogram
+            const f2 u = fma2(splat(fa0.z), pt, fma2(splat(fa0.x), ps, splat(fa0.y)));
+            const f2 v = fma2(splat(fb0.z), pt, fma2(splat(fb0.x), ps, splat(fb0.y)));
+            const f2 w = (splat(1.0f) - u) - v;
+            const f2 u1 = splat(1.0f) - u, v1 = splat(1.0f) - v;
+            const f2 ma = {fminf(fminf(u.x, v.x), w.x), fminf(fminf(u.y, v.y), w.y)};
+            const f2 mb = {fminf(fminf(u1.x, v1.x), -w.x), fminf(fminf(u1.y, v1.y), -w.y)};
+            A = fma2(step01(ma, big), splat(2.0f), step01(mb, big));
+        } else {
+            A = fma2(inside(fa0, fb0), splat(2.0f), inside(fa1, fb1));
         }
-        const int row0 = __float_as_int(ck.x), g0 = __float_as_int(ck.y), count = __float_as_int(ck.z), against = __float_as_int(ck.w);
-        const float offs[8] = {co0.x, co0.y, co0.z, co0.w, co1.x, co1.y, co1.z, co1.w};
-        uint32_t enter = 0;   // wave-uniform: groups that some ray can still improve on
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (j < count) {
-                const f2 t = -(no + splat(offs[j])) * inv;
-                unsigned long long b0 = __builtin_amdgcn_ballot_w64(__float_as_uint(t.x) < best0), b1 = __builtin_amdgcn_ballot_w64(__float_as_uint(t.y) < best1);
-                if constexpr (!NO_CULL) {
-                    const bool ag = (against >> j) & 1;   // wave-uniform
-                    b0 &= ag ? fm0 : fp0; b1 &= ag ? fm1 : fp1;
-                }
-                if ((b0 | b1) != 0ull) enter |= 1u << j;
-            }
+        int k = k0 + 2;
+        for (; k + 1 < k1; k += 2) {
+            const float4 ra0 = tri_uv[2 * k + 0], rb0 = tri_uv[2 * k + 1], ra1 = tri_uv[2 * k + 2], rb1 = tri_uv[2 * k + 3];
+            const f2 f0 = inside(ra0, rb0), f1 = inside(ra1, rb1);
+            A = fma2(A, splat(4.0f), fma2(f0, splat(2.0f), f1));
         }
-        GC_ADD(gc, visited, count);
-        while (enter) {
-            const int j = __builtin_ctz(enter);
-            enter &= enter - 1;
-            const int g = g0 + j;
-            const float4 rk = planes[row0 + 4 * j], w1 = planes[row0 + 4 * j + 1], w2 = planes[row0 + 4 * j + 2], w3 = planes[row0 + 4 * j + 3];
-            // the whole record is asked for in one request, in front of the test (this empty statement needs all of it)
-            asm volatile("" :: "s"(rk.w), "s"(w1.x), "s"(w2.x), "s"(w3.w));
-            const f2 t = -(no + splat(rk.x)) * inv;
-            const uint32_t tp0 = __float_as_uint(t.x), tp1 = __float_as_uint(t.y);
-            bool v0 = tp0 < best0, v1 = tp1 < best1;
-            if constexpr (!NO_CULL) {
-                const bool ag = (against >> j) & 1;
-                v0 &= __builtin_amdgcn_inverse_ballot_w64(ag ? fm0 : fp0); v1 &= __builtin_amdgcn_inverse_ballot_w64(ag ? fm1 : fp1);
-            }
-            if (__builtin_amdgcn_ballot_w64(v0 | v1) == 0ull) continue;  // an earlier group of the class has come closer for every ray
-            GC_ADD(gc, entered, 1);
-            const int k0 = __float_as_int(rk.y), k1 = __float_as_int(rk.z);
-            GC_ADD(gc, steps, (k1 - k0 + 1) / 2);
-            const f2 ps = fma2(ds, t, os), pt = fma2(dt, t, ot);
-            auto inside = [&](float as, float aw, float at, float bs, float bw, float bt) -> f2 {
-                const f2 u = fma2(splat(at), pt, fma2(splat(as), ps, splat(aw)));
-                const f2 v = fma2(splat(bt), pt, fma2(splat(bs), ps, splat(bw)));
-                const f2 w = (splat(1.0f) - u) - v;
-                const f2 m = {fminf(fminf(u.x, v.x), w.x), fminf(fminf(u.y, v.y), w.y)};
-                return step01(m, big);
-            };
-            // two triangles per step; the first step always covers two bit positions (a group of one triangle has
-            // an all-zero second row pair, which is never inside)
-            f2 A;
-            if (__float_as_int(rk.w) != 0) {   // wave-uniform: the first two triangles form a parallelogram
-                const f2 u = fma2(splat(w2.x), pt, fma2(splat(w1.x), ps, splat(w1.y)));
-                const f2 v = fma2(splat(w2.y), pt, fma2(splat(w1.z), ps, splat(w1.w)));
-                const f2 w = (splat(1.0f) - u) - v;
-                const f2 u1 = splat(1.0f) - u, v1 = splat(1.0f) - v;
-                const f2 ma = {fminf(fminf(u.x, v.x), w.x), fminf(fminf(u.y, v.y), w.y)};
-                const f2 mb = {fminf(fminf(u1.x, v1.x), -w.x), fminf(fminf(u1.y, v1.y), -w.y)};
-                A = fma2(step01(ma, big), splat(2.0f), step01(mb, big));
-            } else {
-                A = fma2(inside(w1.x, w1.y, w2.x, w1.z, w1.w, w2.y), splat(2.0f), inside(w2.z, w2.w, w3.z, w3.x, w3.y, w3.w));
-            }
-            int k = k0 + 2;
-            for (; k + 1 < k1; k += 2) {
-                const float4 ra0 = tri_uv[2 * k + 0], rb0 = tri_uv[2 * k + 1], ra1 = tri_uv[2 * k + 2], rb1 = tri_uv[2 * k + 3];
-                const f2 f0 = inside(ra0.x, ra0.y, ra0.z, rb0.x, rb0.y, rb0.z), f1 = inside(ra1.x, ra1.y, ra1.z, rb1.x, rb1.y, rb1.z);
-                A = fma2(A, splat(4.0f), fma2(f0, splat(2.0f), f1));
-            }
-            if (k < k1) {
-                const float4 ra = tri_uv[2 * k + 0], rb = tri_uv[2 * k + 1];
-                A = fma2(A, splat(2.0f), inside(ra.x, ra.y, ra.z, rb.x, rb.y, rb.z));
-            }
-            // closer = some triangle of the group was hit AND the plane is nearer (for this ray, from its front where that counts)
-            const bool cl0 = (A.x >= 1.0f) & v0, cl1 = (A.y >= 1.0f) & v1;
-            best0 = cl0 ? tp0 : best0; A0 = cl0 ? A.x : A0; bg0 = cl0 ? g : bg0;
-            best1 = cl1 ? tp1 : best1; A1 = cl1 ? A.y : A1; bg1 = cl1 ? g : bg1;
-        }
+        if (k < k1) A = fma2(A, splat(2.0f), inside(tri_uv[2 * k + 0], tri_uv[2 * k + 1]));
+        // closer = some triangle of the group was hit AND the plane is nearer (two compares and a scalar AND)
+        const bool cl0 = (A.x >= 1.0f) & (tp0 < best0), cl1 = (A.y >= 1.0f) & (tp1 < best1);
+        best0 = cl0 ? tp0 : best0; A0 = cl0 ? A.x : A0; bg0 = cl0 ? g : bg0;
+        best1 = cl1 ? tp1 : best1; A1 = cl1 ? A.y : A1; bg1 = cl1 ? g : bg1;
     }
 }
 
@@ -447,17 +409,16 @@ __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0
     const f2 dx = {d0.x, d1.x}, dy = {d0.y, d1.y}, dz = {d0.z, d1.z};
     bool any_inside = true;   // wave-uniform
     if constexpr (BOX_FIRST) any_inside = __any((int)ray_meets_scene_box(geo, o0, d0) | (int)ray_meets_scene_box(geo, o1, d1));
+    const f2 cull = {back_cull0 ? 0.0f : __builtin_inff(), back_cull1 ? 0.0f : __builtin_inff()};
     const f2 big = splat(0x1p126f);
-    // lanes whose ray counts both sides of every face (lane masks)
-    const unsigned long long nocull0 = ~__builtin_amdgcn_ballot_w64(back_cull0), nocull1 = ~__builtin_amdgcn_ballot_w64(back_cull1);
     uint32_t best0 = __float_as_uint(bound0), best1 = __float_as_uint(bound1);
     float A0 = 0.0f, A1 = 0.0f;
     int bg0 = 0, bg1 = 0;
     int prim0 = -1, prim1 = -1, back0 = 0, back1 = 0;
     if (any_inside) {
-    plane_groups<0, NO_CULL>(planes, plane_first, tri_uv, 0, geo.axis_end[0], ox, oy, oz, dx, dy, dz, nocull0, nocull1, big, best0, best1, A0, A1, bg0, bg1, gc);
-    plane_groups<1, NO_CULL>(planes, plane_first, tri_uv, geo.axis_end[0], geo.axis_end[1], ox, oy, oz, dx, dy, dz, nocull0, nocull1, big, best0, best1, A0, A1, bg0, bg1, gc);
-    plane_groups<2, NO_CULL>(planes, plane_first, tri_uv, geo.axis_end[1], geo.axis_end[2], ox, oy, oz, dx, dy, dz, nocull0, nocull1, big, best0, best1, A0, A1, bg0, bg1, gc);
+    plane_groups<0, NO_CULL>(planes, plane_first, tri_uv, 0, geo.axis_end[0], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1, gc);
+    plane_groups<1, NO_CULL>(planes, plane_first, tri_uv, geo.axis_end[0], geo.axis_end[1], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1, gc);
+    plane_groups<2, NO_CULL>(planes, plane_first, tri_uv, geo.axis_end[1], geo.axis_end[2], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1, gc);
     if (A0 >= 1.0f) prim0 = first_hit_of_group(plane_first, bg0, A0);   // some group was hit (its hit bits are kept with it)
     if (A1 >= 1.0f) prim1 = first_hit_of_group(plane_first, bg1, A1);
     // Spheres and lights.  getSphereCollision (T3DR.py:572-598), Ray.getTSphere (T3DE.py:145-163).
@@ -737,11 +698,6 @@ __device__ __forceinline__ ShadowRay shadow_ray(const DevLight lt, float4 ra, fl
     s.start = madd(s.P, s.Ld, 0.2f);  // T3DR.py:840
     s.strength = lt.strength;
     s.reach = fmaf(fmaxf(s.dist2 * __builtin_amdgcn_rsqf(s.dist2) - 0.2f, 0.0f), 1.0001f, 1e-3f);
-    // A ray that leaves its surface at a grazing angle (within 1e-4 of the tangent plane) is not given a bound: where the
-    // light is a face in the node's own plane -- the lamp in a ceiling, seen from the ceiling -- such a ray runs inside the
-    // lamp's plane, meets nothing there (T3DR.py:636) and goes on to the far wall like the reference's.
-    const float tn = dot(s.to, s.N);
-    if (tn * tn < 1e-8f * s.dist2) s.reach = __builtin_inff();
     return s;
 }
 __device__ __forceinline__ ShadowRay shadow_ray(const DevScene& sc, float4 ra, float4 rb, int l) { return shadow_ray(sc.lights[l], ra, rb); }
@@ -2107,138 +2063,105 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
         }
     }
     if (n_owned != s->n_tris) { c->err = "t3d_upload_scene: triangles not owned by any mesh object"; return T3D_E_INVALID; }
-    // Direction classes: groups whose planes are parallel (the same unit normal up to its sign, to 1e-10) are visited
-    // together, see plane_groups.  A class has one axis -- that of its normal's largest component, which is dropped for
-    // the in-plane coordinates of its triangles -- and one unit normal n^; a group lies at offset `off` along it
-    // (n^.x + off = 0) and faces along n^ or against it.
-    struct Dir { double n[3]; int axis; };
-    std::vector<Dir> dirs;
-    std::vector<int> group_dir(groups.size(), -1);
-    std::vector<char> group_against(groups.size(), 0);
-    std::vector<double> group_off(groups.size(), 0.0);
-    {
-        std::map<std::tuple<long long, long long, long long>, std::vector<int>> by_key;
+    // Device order of the groups: by the axis of the largest normal component (that axis is dropped for the
+    // in-plane coordinates), groups of one axis in order of their first triangle; groups of more than 24
+    // triangles are cut into pieces (the hit flags of a group are the bits of a float32 integer).
+    struct Piece { int group, first, count, axis; };
+    std::vector<Piece> pieces;
+    int axis_count[3] = {0, 0, 0};
+    for (int ax = 0; ax < 3; ++ax) {
         for (size_t g = 0; g < groups.size(); ++g) {
             const Tri& F = tris[groups[g][0]];
-            const double len = sqrt(F.n[0] * F.n[0] + F.n[1] * F.n[1] + F.n[2] * F.n[2]);
-            if (!(len > 0)) {   // degenerate: a class of its own whose normal is zero, so that nothing ever hits it
-                group_dir[g] = (int)dirs.size();
-                dirs.push_back(Dir{{0, 0, 0}, 0});
-                continue;
+            int gax = 0;
+            if (fabs(F.n[1]) > fabs(F.n[gax])) gax = 1;
+            if (fabs(F.n[2]) > fabs(F.n[gax])) gax = 2;
+            if (gax != ax) continue;
+            for (int first = 0; first < (int)groups[g].size(); first += 24) {
+                int cnt = (int)groups[g].size() - first;
+                pieces.push_back(Piece{(int)g, first, cnt > 24 ? 24 : cnt, ax});
+                axis_count[ax]++;
             }
-            double u[3] = {F.n[0] / len, F.n[1] / len, F.n[2] / len};
-            int ax = 0;
-            if (fabs(u[1]) > fabs(u[ax])) ax = 1;
-            if (fabs(u[2]) > fabs(u[ax])) ax = 2;
-            const double sgn = u[ax] < 0 ? -1.0 : 1.0;   // the class's normal has its largest component positive
-            const auto key = std::make_tuple(llround(sgn * u[0] * 1e6), llround(sgn * u[1] * 1e6), llround(sgn * u[2] * 1e6));
-            int found = -1;
-            for (int d : by_key[key]) {
-                const double* m = dirs[d].n;
-                const double cx = u[1] * m[2] - u[2] * m[1], cy = u[2] * m[0] - u[0] * m[2], cz = u[0] * m[1] - u[1] * m[0];
-                if (cx * cx + cy * cy + cz * cz < 1e-20) { found = d; break; }
-            }
-            if (found < 0) {
-                found = (int)dirs.size();
-                dirs.push_back(Dir{{sgn * u[0], sgn * u[1], sgn * u[2]}, ax});
-                by_key[key].push_back(found);
-            }
-            const double* m = dirs[found].n;
-            const bool against = u[0] * m[0] + u[1] * m[1] + u[2] * m[2] < 0;
-            group_dir[g] = found;
-            group_against[g] = against;
-            group_off[g] = -(against ? -1.0 : 1.0) * F.nv0 / len;
         }
     }
-    // Pieces: groups of more than 24 triangles are cut (the hit flags of a group are the bits of a float32 integer).
-    struct Piece { int group, first, count, axis, dir; };
-    std::vector<Piece> pieces;
-    for (size_t g = 0; g < groups.size(); ++g)
-        for (int first = 0; first < (int)groups[g].size(); first += 24) {
-            const int cnt = (int)groups[g].size() - first;
-            pieces.push_back(Piece{(int)g, first, cnt > 24 ? 24 : cnt, dirs[group_dir[g]].axis, group_dir[g]});
-        }
-    // Device order: by axis; within an axis the classes, and within a class its planes, in the order of how often they
-    // hold the closest hit, most often first: a plane that cannot beat the best distance found so far is skipped by the
-    // whole wave, so the sooner the near surfaces are tested, the more of the others are skipped.  The frequencies come
-    // from a few thousand rays between random points of the triangles (float64, deterministic).  Planes that coincide --
-    // the pieces of one group, two faces back to back -- stay together in their original order, which decides who wins a
-    // tie in distance (T3DR.py:715).
-    {
+    // Within an axis the pieces are visited in the order of how often they hold the closest hit, most often first: a plane
+    // that cannot beat the best distance found so far is skipped by the whole wave, so the sooner the near surfaces are
+    // tested, the more of the others are skipped.  The frequencies come from a few thousand rays between random points
+    // of the triangles (float64, deterministic).  Planes that coincide -- the pieces of one group, two faces back to back
+    // -- keep their original order, which decides who wins a tie in distance (T3DR.py:715).
+    if (!want_bvh && pieces.size() > 2 && !getenv("T3D_KEEP_GROUP_ORDER")) {
         const size_t P = pieces.size();
+        std::vector<int> piece_of_tri((size_t)s->n_tris, -1);
+        for (size_t q = 0; q < P; ++q)
+            for (int j = 0; j < pieces[q].count; ++j) piece_of_tri[groups[pieces[q].group][pieces[q].first + j]] = (int)q;
         std::vector<double> weight(P, 0.0);
-        if (!want_bvh && P > 2 && !getenv("T3D_KEEP_GROUP_ORDER")) {
-            std::vector<int> piece_of_tri((size_t)s->n_tris, -1);
-            for (size_t q = 0; q < P; ++q)
-                for (int j = 0; j < pieces[q].count; ++j) piece_of_tri[groups[pieces[q].group][pieces[q].first + j]] = (int)q;
-            uint64_t rng = 0x9E3779B97F4A7C15ull;
-            auto uni = [&]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (double)(rng >> 11) * (1.0 / 9007199254740992.0); };
-            auto point_on = [&](int t, double* p) {
+        uint64_t rng = 0x9E3779B97F4A7C15ull;
+        auto uni = [&]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (double)(rng >> 11) * (1.0 / 9007199254740992.0); };
+        auto point_on = [&](int t, double* p) {
+            const double* v = s->tri_verts + 9 * (size_t)t;
+            double a = uni(), b = uni();
+            if (a + b > 1) { a = 1 - a; b = 1 - b; }
+            for (int k = 0; k < 3; ++k) p[k] = v[k] + a * (v[3 + k] - v[k]) + b * (v[6 + k] - v[k]);
+        };
+        const int n_samples = 4096;
+        for (int it = 0; it < n_samples && s->n_tris > 1; ++it) {
+            const int ta = (int)(uni() * s->n_tris) % s->n_tris, tb = (int)(uni() * s->n_tris) % s->n_tris;
+            double o[3], e[3], d[3];
+            point_on(ta, o); point_on(tb, e);
+            double len = 0;
+            for (int k = 0; k < 3; ++k) { d[k] = e[k] - o[k]; len += d[k] * d[k]; }
+            if (!(len > 1e-20)) continue;
+            len = sqrt(len);
+            for (int k = 0; k < 3; ++k) { d[k] /= len; o[k] += 1e-3 * len * d[k]; }
+            double best = INFINITY; int hit = -1;
+            for (int t = 0; t < s->n_tris; ++t) {
+                const Tri& T = tris[t];
+                const double dn = T.n[0] * d[0] + T.n[1] * d[1] + T.n[2] * d[2];
+                if (fabs(dn) < 1e-12) continue;
+                const double tt = (T.nv0 - (T.n[0] * o[0] + T.n[1] * o[1] + T.n[2] * o[2])) / dn;
+                if (!(tt > 0) || tt >= best) continue;
                 const double* v = s->tri_verts + 9 * (size_t)t;
-                double a = uni(), b = uni();
-                if (a + b > 1) { a = 1 - a; b = 1 - b; }
-                for (int k = 0; k < 3; ++k) p[k] = v[k] + a * (v[3 + k] - v[k]) + b * (v[6 + k] - v[k]);
-            };
-            const int n_samples = 4096;
-            for (int it = 0; it < n_samples && s->n_tris > 1; ++it) {
-                const int ta = (int)(uni() * s->n_tris) % s->n_tris, tb = (int)(uni() * s->n_tris) % s->n_tris;
-                double o[3], e[3], d[3];
-                point_on(ta, o); point_on(tb, e);
-                double len = 0;
-                for (int k = 0; k < 3; ++k) { d[k] = e[k] - o[k]; len += d[k] * d[k]; }
-                if (!(len > 1e-20)) continue;
-                len = sqrt(len);
-                for (int k = 0; k < 3; ++k) { d[k] /= len; o[k] += 1e-3 * len * d[k]; }
-                double best = INFINITY; int hit = -1;
-                for (int t = 0; t < s->n_tris; ++t) {
-                    const Tri& T = tris[t];
-                    const double dn = T.n[0] * d[0] + T.n[1] * d[1] + T.n[2] * d[2];
-                    if (fabs(dn) < 1e-12) continue;
-                    const double tt = (T.nv0 - (T.n[0] * o[0] + T.n[1] * o[1] + T.n[2] * o[2])) / dn;
-                    if (!(tt > 0) || tt >= best) continue;
-                    const double* v = s->tri_verts + 9 * (size_t)t;
-                    double pnt[3], c0[3], c1[3], c2[3];
-                    for (int k = 0; k < 3; ++k) pnt[k] = o[k] + tt * d[k];
-                    auto edge = [&](const double* a, const double* b, double* out) {   // (b - a) x (P - a)
-                        const double u[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, w[3] = {pnt[0] - a[0], pnt[1] - a[1], pnt[2] - a[2]};
-                        out[0] = u[1] * w[2] - u[2] * w[1]; out[1] = u[2] * w[0] - u[0] * w[2]; out[2] = u[0] * w[1] - u[1] * w[0];
-                    };
-                    edge(v, v + 3, c0); edge(v + 3, v + 6, c1); edge(v + 6, v, c2);
-                    if (c0[0] * c1[0] + c0[1] * c1[1] + c0[2] * c1[2] > 0 && c1[0] * c2[0] + c1[1] * c2[1] + c1[2] * c2[2] > 0) { best = tt; hit = t; }
-                }
-                if (hit >= 0 && piece_of_tri[hit] >= 0) weight[piece_of_tri[hit]] += 1.0;
+                double pnt[3], c0[3], c1[3], c2[3];
+                for (int k = 0; k < 3; ++k) pnt[k] = o[k] + tt * d[k];
+                auto edge = [&](const double* a, const double* b, double* out) {   // (b - a) x (P - a)
+                    const double u[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, w[3] = {pnt[0] - a[0], pnt[1] - a[1], pnt[2] - a[2]};
+                    out[0] = u[1] * w[2] - u[2] * w[1]; out[1] = u[2] * w[0] - u[0] * w[2]; out[2] = u[0] * w[1] - u[1] * w[0];
+                };
+                edge(v, v + 3, c0); edge(v + 3, v + 6, c1); edge(v + 6, v, c2);
+                if (c0[0] * c1[0] + c0[1] * c1[1] + c0[2] * c1[2] > 0 && c1[0] * c2[0] + c1[1] * c2[1] + c1[2] * c2[2] > 0) { best = tt; hit = t; }
             }
+            if (hit >= 0 && piece_of_tri[hit] >= 0) weight[piece_of_tri[hit]] += 1.0;
         }
-        // sets of coinciding planes within a class (union-find over the pieces of the class)
+        // classes of coinciding planes (union-find over the pieces)
         std::vector<int> cls(P);
         for (size_t q = 0; q < P; ++q) cls[q] = (int)q;
         std::function<int(int)> find = [&](int x) { while (cls[x] != x) x = cls[x] = cls[cls[x]]; return x; };
-        std::vector<std::vector<int>> of_dir(dirs.size());
-        for (size_t q = 0; q < P; ++q) of_dir[pieces[q].dir].push_back((int)q);
-        for (const auto& members : of_dir)
-            for (size_t i = 0; i < members.size(); ++i)
-                for (size_t k = i + 1; k < members.size(); ++k) {
-                    const int a = members[i], b = members[k];
-                    const double oa = group_off[pieces[a].group], ob = group_off[pieces[b].group];
-                    const double scale = fmax(1.0, fmax(fabs(oa), fabs(ob)));
-                    if (pieces[a].group == pieces[b].group || fabs(oa - ob) < 1e-5 * scale) cls[find(b)] = find(a);
-                }
-        std::vector<double> cls_weight(P, 0.0), dir_weight(dirs.size(), 0.0);
-        std::vector<int> cls_first(P, (int)P), dir_first(dirs.size(), (int)P);
-        for (size_t q = 0; q < P; ++q) {
-            const int r = find((int)q);
-            cls_weight[r] += weight[q]; cls_first[r] = std::min(cls_first[r], (int)q);
-            dir_weight[pieces[q].dir] += weight[q]; dir_first[pieces[q].dir] = std::min(dir_first[pieces[q].dir], (int)q);
+        auto unit_plane = [&](size_t q, double* n, double& off) {
+            const Tri& F = tris[groups[pieces[q].group][0]];
+            const double len = sqrt(F.n[0] * F.n[0] + F.n[1] * F.n[1] + F.n[2] * F.n[2]);
+            if (!(len > 0)) return false;
+            for (int k = 0; k < 3; ++k) n[k] = F.n[k] / len;
+            off = F.nv0 / len;
+            return true;
+        };
+        for (size_t a = 0; a < P; ++a) {
+            double na[3], oa;
+            if (!unit_plane(a, na, oa)) continue;
+            for (size_t b = a + 1; b < P; ++b) {
+                if (pieces[a].axis != pieces[b].axis) continue;
+                double nb[3], ob;
+                if (!unit_plane(b, nb, ob)) continue;
+                const double dt = na[0] * nb[0] + na[1] * nb[1] + na[2] * nb[2];
+                const double scale = fmax(1.0, fmax(fabs(oa), fabs(ob)));
+                if (pieces[a].group == pieces[b].group || (fabs(dt) > 1 - 1e-9 && fabs(oa - (dt > 0 ? ob : -ob)) < 1e-5 * scale)) cls[find((int)b)] = find((int)a);
+            }
         }
+        std::vector<double> cls_weight(P, 0.0);
+        std::vector<int> cls_first(P, (int)P);
+        for (size_t q = 0; q < P; ++q) { const int r = find((int)q); cls_weight[r] += weight[q]; cls_first[r] = std::min(cls_first[r], (int)q); }
         std::vector<int> idx(P);
         for (size_t q = 0; q < P; ++q) idx[q] = (int)q;
         std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
             if (pieces[a].axis != pieces[b].axis) return pieces[a].axis < pieces[b].axis;
-            const int da = pieces[a].dir, db = pieces[b].dir;
-            if (da != db) {
-                if (dir_weight[da] != dir_weight[db]) return dir_weight[da] > dir_weight[db];
-                return dir_first[da] < dir_first[db];
-            }
             const int ra = find(a), rb = find(b);
             if (ra == rb) return a < b;
             if (cls_weight[ra] != cls_weight[rb]) return cls_weight[ra] > cls_weight[rb];
@@ -2247,69 +2170,23 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
         std::vector<Piece> sorted(P);
         for (size_t q = 0; q < P; ++q) sorted[q] = pieces[idx[q]];
         pieces.swap(sorted);
-        // planes that coincide share one offset value, so that their distances are equal bit for bit and the first one
-        // visited keeps a hit, as in the reference
-        std::map<int, double> set_off;
-        for (size_t q = 0; q < P; ++q) {
-            const int r = find(idx[q]);
-            auto it = set_off.find(r);
-            if (it == set_off.end()) set_off.emplace(r, group_off[pieces[q].group]);
-            else group_off[pieces[q].group] = it->second;
-        }
     }
     const size_t G = pieces.size();
-    // class records: a class of more than eight planes takes several
-    struct ClassRec { int first, count; };
-    std::vector<ClassRec> class_recs;
-    int axis_count[3] = {0, 0, 0};
-    for (size_t g = 0; g < G; ++g) {
-        if (class_recs.empty() || pieces[g].dir != pieces[class_recs.back().first].dir || class_recs.back().count == 8) {
-            class_recs.push_back(ClassRec{(int)g, 0});
-            axis_count[pieces[g].axis]++;
-        }
-        class_recs.back().count++;
-    }
-    const size_t C = class_recs.size();
-    // `planes`: the class records, then one record per group (layouts: plane_groups); one more of each, all zero
-    std::vector<float4> planes(4 * (C + 1) + 4 * (G + 1), make_float4(0.f, 0.f, 0.f, 0.f));
-    const size_t group_rows = 4 * (C + 1);
+    std::vector<float4> planes(6 * (G + 1), make_float4(0.f, 0.f, 0.f, 0.f));
     std::vector<int> plane_first(G + 1, 0);
     std::vector<float4> tri_uv((size_t)2 * (s->n_tris + 1), make_float4(0.f, 0.f, 0.f, 0.f));
     std::vector<float4> tri_n((size_t)s->n_tris + 1, make_float4(0.f, 0.f, 0.f, 0.f));
     std::vector<int4> meta((size_t)s->n_tris + 1, make_int4(0, 0, 0, 0));
     std::vector<int> order((size_t)s->n_tris + 1, 0);  // device position -> index in the description
     {
-        auto ib = [](int v) { return __builtin_bit_cast(float, v); };
-        for (size_t ci = 0; ci < C; ++ci) {
-            const ClassRec& cr = class_recs[ci];
-            const Piece& p0 = pieces[cr.first];
-            const Dir& D = dirs[p0.dir];
-            const Tri& F = tris[groups[p0.group][0]];
-            const double nn = F.n[0] * F.n[0] + F.n[1] * F.n[1] + F.n[2] * F.n[2];
-            // |d.n| < 1e-6 on the un-normalised normal (T3DR.py:636) is |d.n^| < 1e-6 / |n|
-            const float neg_thr2 = nn > 0 ? -(float)(1e-12 / nn) : -1.0f;
-            int against = 0;
-            float offs[8];
-            for (int j = 0; j < 8; ++j) offs[j] = __builtin_nanf("");
-            for (int j = 0; j < cr.count; ++j) {
-                const Piece& pc = pieces[cr.first + j];
-                against |= (int)group_against[pc.group] << j;
-                offs[j] = (float)group_off[pc.group] + 0.0f;
-            }
-            planes[4 * ci + 0] = make_float4((float)D.n[0], (float)D.n[1], (float)D.n[2], neg_thr2);
-            planes[4 * ci + 1] = make_float4(ib((int)(group_rows + 4 * (size_t)cr.first)), ib(cr.first), ib(cr.count), ib(against));
-            planes[4 * ci + 2] = make_float4(offs[0], offs[1], offs[2], offs[3]);
-            planes[4 * ci + 3] = make_float4(offs[4], offs[5], offs[6], offs[7]);
-        }
-        // the first two triangles of a group travel in its record: a_s, aw, b_s, bw, a_t, b_t each
-        auto put_rows = [&](size_t g, int j, float4 ra, float4 rb) {
-            float* w = &planes[group_rows + 4 * g + 1].x + 6 * j;
-            w[0] = ra.x; w[1] = ra.y; w[2] = rb.x; w[3] = rb.y; w[4] = ra.z; w[5] = rb.z;
-        };
         int k = 0;
         for (size_t g = 0; g < G; ++g) {
             const Piece& pc = pieces[g];
-            planes[group_rows + 4 * g] = make_float4((float)group_off[pc.group] + 0.0f, ib(k), ib(k + pc.count), ib(0));
+            const Tri& F = tris[groups[pc.group][0]];
+            // rows are stored (x, offset, y, z): the first fma of a dot product then takes its factor and its
+            // addend from one aligned SGPR pair; "+ 0.0f" turns a -0 offset into +0
+            planes[6 * g] = make_float4((float)F.n[0], -(float)F.nv0 + 0.0f, (float)F.n[1], (float)F.n[2]);
+            planes[6 * g + 1] = make_float4(__builtin_bit_cast(float, k), __builtin_bit_cast(float, k + pc.count), 0.f, 0.f);
             plane_first[g] = k;
             const int i1 = (pc.axis + 1) % 3, i2 = (pc.axis + 2) % 3;  // in-plane coordinates (s, t)
             for (int j = 0; j < pc.count; ++j) {
@@ -2325,7 +2202,7 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
                     tri_uv[2 * (size_t)k + 0] = make_float4((float)as, (float)aw + 0.0f, (float)at, 0.f);
                     tri_uv[2 * (size_t)k + 1] = make_float4((float)bs, (float)bw + 0.0f, (float)bt, 0.f);
                 }   // else: degenerate triangle, rows stay zero and min3(u, v, w) = 0 never counts as inside
-                if (j < 2) put_rows(g, j, tri_uv[2 * (size_t)k + 0], tri_uv[2 * (size_t)k + 1]);
+                if (j < 2) { planes[6 * g + 2 + 2 * j] = tri_uv[2 * (size_t)k + 0]; planes[6 * g + 3 + 2 * j] = tri_uv[2 * (size_t)k + 1]; }
                 tri_n[k] = make_float4((float)T.n[0], (float)T.n[1], (float)T.n[2], -(float)T.nv0 + 0.0f);
                 order[k] = t;
                 meta[k] = make_int4(T.obj, T.face, T.shader, t);
@@ -2356,11 +2233,11 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
                 for (int j = 0; j < 3; ++j)
                     if (A[3 * i] == B[3 * j] && A[3 * i + 1] == B[3 * j + 1] && A[3 * i + 2] == B[3 * j + 2]) { shared_a |= 1 << i; shared_b |= 1 << j; ++n_shared; }
             if (n_shared != 2 || __builtin_popcount(shared_a) != 2 || __builtin_popcount(shared_b) != 2) continue;
-            const int ia = shared_a == 6 ? 0 : (shared_a == 5 ? 1 : 2), ib2 = shared_b == 6 ? 0 : (shared_b == 5 ? 1 : 2);  // the lone corners
+            const int ia = shared_a == 6 ? 0 : (shared_a == 5 ? 1 : 2), ib = shared_b == 6 ? 0 : (shared_b == 5 ? 1 : 2);  // the lone corners
             const int i1a = (ia + 1) % 3, i2a = (ia + 2) % 3;
             double scale = 0, err = 0;
             for (int c3 = 0; c3 < 3; ++c3) {
-                const double sum_diag = A[3 * i1a + c3] + A[3 * i2a + c3], sum_lone = A[3 * ia + c3] + B[3 * ib2 + c3];
+                const double sum_diag = A[3 * i1a + c3] + A[3 * i2a + c3], sum_lone = A[3 * ia + c3] + B[3 * ib + c3];
                 err = fmax(err, fabs(sum_diag - sum_lone));
                 scale = fmax(scale, fmax(fabs(sum_diag), fabs(A[3 * i1a + c3] - A[3 * i2a + c3])));
             }
@@ -2372,8 +2249,9 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
             if (det == 0.0) continue;
             const double as = e2t / det, at = -e2s / det, bs = -e1t / det, bt = e1s / det;
             const double aw = -(as * v0[i1] + at * v0[i2]), bw = -(bs * v0[i1] + bt * v0[i2]);
-            put_rows(g, 0, make_float4((float)as, (float)aw + 0.0f, (float)at, 0.f), make_float4((float)bs, (float)bw + 0.0f, (float)bt, 0.f));
-            planes[group_rows + 4 * g].w = ib(1);
+            planes[6 * g + 2] = make_float4((float)as, (float)aw + 0.0f, (float)at, 0.f);
+            planes[6 * g + 3] = make_float4((float)bs, (float)bw + 0.0f, (float)bt, 0.f);
+            planes[6 * g + 1].z = __builtin_bit_cast(float, 1);
         }
     }
     std::vector<DevShader> shaders((size_t)s->n_shaders);
@@ -2441,7 +2319,7 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
     DevScene& d = c->sc;
     d.bvh.nodes = (const float4*)c->d_bvh_nodes; d.bvh.leaves = (const float4*)c->d_bvh_leaves; d.bvh.n_prims = n_prims;
     d.bvh.spill = (int*)c->d_bvh_spill;
-    d.geo.axis_end[0] = axis_count[0]; d.geo.axis_end[1] = axis_count[0] + axis_count[1]; d.geo.axis_end[2] = (int)C;
+    d.geo.axis_end[0] = axis_count[0]; d.geo.axis_end[1] = axis_count[0] + axis_count[1]; d.geo.axis_end[2] = (int)G;
     d.geo.n_tris = s->n_tris; d.geo.n_spheres = (int)spheres.size();
     for (int a = 0; a < 3; ++a) { c->tri_lo[a] = INFINITY; c->tri_hi[a] = -INFINITY; }
     for (size_t q = 0; q < (size_t)s->n_tris * 9; ++q) { c->tri_lo[q % 3] = fmin(c->tri_lo[q % 3], s->tri_verts[q]); c->tri_hi[q % 3] = fmax(c->tri_hi[q % 3], s->tri_verts[q]); }
