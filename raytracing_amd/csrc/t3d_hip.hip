@@ -95,7 +95,8 @@ struct DevCamera {
 // that the compiler may use scalar loads for it.
 //   planes      [6G]  per coplanar group a 96-byte record: (n.x, -n.v0, n.y, n.z) of its first triangle, un-normalised
 //                     like MathematicalPlane.normal (T3DE.py:251-263); (first, end) of its triangle range as int
-//                     bits and a parallelogram flag; the tri_uv rows of its first two triangles (zeros where the
+//                     bits, a parallelogram flag and the range once more as first | count << 26 (what a ray keeps of the
+//                     group it hit); the tri_uv rows of its first two triangles (zeros where the
 //                     group has only one; for a parallelogram only the first triangle's, see t3d_upload_scene)
 //   plane_first [G+1] triangle range of each group
 //   tri_uv      [2T]  per triangle (a_s, aw, a_t, 0), (b_s, bw, b_t, 0): barycentric rows in the two in-plane
@@ -125,11 +126,12 @@ struct DevScene {
     const DevLight* lights;    // [L]
     const DevShader* shaders;  // [K]
     const float* obj_ior;      // [O]
-    const float4* prim_info;   // [3 (T + S)]: what the classification of a hit needs about its primitive, gathered in one go
+    const float4* prim_info;   // [4 (T + S)]: what the classification of a hit needs about its primitive, gathered in one go
                                //   row 0: the triangle's unit normal (sphere: its centre), w = ior of the primitive's object
                                //   row 1: int bits: object, face in its mesh (sphere: -1), shader, kind (bit 0 emitter, bit 1 sphere)
                                //   row 2: roughness, reflectivity, emission strength (Light: its strength),
                                //          visibility a shadow ray is left with when this primitive is the first thing it hits
+                               //   row 3: colour of its shader (what an emitter shows, T3DR.py:1014-1041)
     DevCamera cam;
     float light_color[3];  // sum over lights of colour * 0.6 with saturating adds (T3DR.py:893)
 };
@@ -366,14 +368,17 @@ __device__ __forceinline__ void plane_groups(const float4* __restrict__ planes, 
         if (k < k1) A = fma2(A, splat(2.0f), inside(tri_uv[2 * k + 0], tri_uv[2 * k + 1]));
         // closer = some triangle of the group was hit AND the plane is nearer (two compares and a scalar AND)
         const bool cl0 = (A.x >= 1.0f) & (tp0 < best0), cl1 = (A.y >= 1.0f) & (tp1 < best1);
-        best0 = cl0 ? tp0 : best0; A0 = cl0 ? A.x : A0; bg0 = cl0 ? g : bg0;
-        best1 = cl1 ? tp1 : best1; A1 = cl1 ? A.y : A1; bg1 = cl1 ? g : bg1;
+        // (what is kept of the group is its triangle range as the record packs it: first triangle | count << 26)
+        const int range = __float_as_int(rk.w);
+        best0 = cl0 ? tp0 : best0; A0 = cl0 ? A.x : A0; bg0 = cl0 ? range : bg0;
+        best1 = cl1 ? tp1 : best1; A1 = cl1 ? A.y : A1; bg1 = cl1 ? range : bg1;
     }
 }
 
 // Triangle index from the hit bits of its group: bit (n-1-j) stands for the j-th triangle of the group.
-__device__ __forceinline__ int first_hit_of_group(const int* __restrict__ plane_first, int g, float A) {
-    const int k0 = plane_first[g], n = plane_first[g + 1] - k0;
+// (range: the group's first triangle | its triangle count << 26, from its record)
+__device__ __forceinline__ int first_hit_of_group(int range, float A) {
+    const int k0 = range & 0x3FFFFFF, n = (int)((uint32_t)range >> 26);
     const int width = n > 2 ? n : 2;  // bit positions used by the group: the first step always takes two
     int j = width - 1 - ((int)(__float_as_uint(A) >> 23) - 127);
     j = j < 0 ? 0 : (j > n - 1 ? n - 1 : j);
@@ -419,8 +424,8 @@ __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0
     plane_groups<0, NO_CULL>(planes, plane_first, tri_uv, 0, geo.axis_end[0], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1, gc);
     plane_groups<1, NO_CULL>(planes, plane_first, tri_uv, geo.axis_end[0], geo.axis_end[1], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1, gc);
     plane_groups<2, NO_CULL>(planes, plane_first, tri_uv, geo.axis_end[1], geo.axis_end[2], ox, oy, oz, dx, dy, dz, cull, big, best0, best1, A0, A1, bg0, bg1, gc);
-    if (A0 >= 1.0f) prim0 = first_hit_of_group(plane_first, bg0, A0);   // some group was hit (its hit bits are kept with it)
-    if (A1 >= 1.0f) prim1 = first_hit_of_group(plane_first, bg1, A1);
+    if (A0 >= 1.0f) prim0 = first_hit_of_group(bg0, A0);   // some group was hit (its hit bits and its triangle range are kept with it)
+    if (A1 >= 1.0f) prim1 = first_hit_of_group(bg1, A1);
     // Spheres and lights.  getSphereCollision (T3DR.py:572-598), Ray.getTSphere (T3DE.py:145-163).
     const int n_tris = geo.n_tris;
     for (int s = 0; s < geo.n_spheres; ++s) {
@@ -745,7 +750,7 @@ __device__ __forceinline__ bool shadow_dead(const DevScene& sc, const ShadowRay&
 __device__ __forceinline__ float shadow_intensity(const DevScene& sc, const DevSphere* __restrict__ spheres, const ShadowRay& s,
                                                   const Hit& h) {
     // getVisibility (T3DR.py:762-778): 1 - reflectivity of the first thing hit unless that is a light or an emissive face
-    const float vis = h.prim >= 0 ? sc.prim_info[3 * (size_t)h.prim + 2].w : 1.0f;
+    const float vis = h.prim >= 0 ? sc.prim_info[4 * (size_t)h.prim + 2].w : 1.0f;
     return shadow_facing(sc, s) * s.strength * vis * attenuation(s.dist2);
 }
 
@@ -829,8 +834,9 @@ __device__ __forceinline__ Outcome hit_outcome(const DevScene& sc, const RenderP
     float strength = 1.0f, refl = 1.0f;
     r.rough = 1.0f; r.obj_ior = 1.0f;
     if (r.hit) {
-        const float4* __restrict__ info = sc.prim_info + 3 * (size_t)h.prim;
-        const float4 i0 = info[0], i1 = info[1], i2 = info[2];
+        const float4* __restrict__ info = sc.prim_info + 4 * (size_t)h.prim;
+        const float4 i0 = info[0], i1 = info[1], i2 = info[2], i3 = info[3];
+        asm volatile("" :: "v"(i3.x));   // all four rows in flight together: an emitter's colour is not fetched behind the test for one
         const int kind = __float_as_int(i1.w);
         r.obj = __float_as_int(i1.x); r.face = __float_as_int(i1.y); r.shader = __float_as_int(i1.z);
         if (!(kind & 2)) {
@@ -850,11 +856,10 @@ __device__ __forceinline__ Outcome hit_outcome(const DevScene& sc, const RenderP
         r.rough = i2.x; refl = i2.y; r.obj_ior = i0.w;
         if (r.emitter) {
             // computeColor for lights / emissive faces (T3DR.py:1014-1041): distance to the camera
-            DevShader sh = sc.shaders[r.shader];
             V3 pc = mk(r.P.x - sc.cam.pos[0], r.P.y - sc.cam.pos[1], r.P.z - sc.cam.pos[2]);
             float att = attenuation(dot(pc, pc));
-            r.emit = mk(fminf(sh.r * strength * att, 255.0f), fminf(sh.g * strength * att, 255.0f),
-                        fminf(sh.b * strength * att, 255.0f));
+            r.emit = mk(fminf(i3.x * strength * att, 255.0f), fminf(i3.y * strength * att, 255.0f),
+                        fminf(i3.z * strength * att, 255.0f));
         }
     }
     if (level0 && in.active) {
@@ -1962,13 +1967,14 @@ static std::vector<DevLight> make_lights(DevScene& d, const t3d_scene_desc* s) {
     for (int k = 0; k < 3; ++k) d.light_color[k] = (float)lc[k];
     return lights;
 }
-// the three prim_info rows of a sphere or Light
+// the four prim_info rows of a sphere or Light
 static void sphere_rows(const DevSphere& sp, const t3d_scene_desc* s, float4* rows) {
     auto ib = [](int v) { return __builtin_bit_cast(float, v); };
     const float rough = (float)s->shader_rough[sp.shader], refl = (float)s->shader_refl[sp.shader];
     rows[0] = make_float4(sp.cx, sp.cy, sp.cz, (float)s->obj_ior[sp.obj]);
     rows[1] = make_float4(ib(sp.obj), ib(-1), ib(sp.shader), ib(2 | (sp.is_light ? 1 : 0)));
     rows[2] = make_float4(rough, refl, sp.strength, sp.is_light ? 1.0f : 1.0f - refl);
+    rows[3] = make_float4((float)s->shader_color[3 * sp.shader], (float)s->shader_color[3 * sp.shader + 1], (float)s->shader_color[3 * sp.shader + 2], 0.f);
 }
 static const char* not_finite(const t3d_scene_desc* s, bool triangles) {
     auto finite = [](const double* p, size_t n) { if (p) for (size_t i = 0; i < n; ++i) if (!std::isfinite(p[i])) return false; return true; };
@@ -2019,6 +2025,7 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
     int n_prims = s->n_tris;
     for (int o = 0; o < s->n_objects; ++o) n_prims += s->obj_type[o] == T3D_OBJ_SPHERE || s->obj_type[o] == T3D_OBJ_LIGHT;
     const bool want_bvh = n_prims >= 2 && (c->accel == T3D_ACCEL_LBVH || (c->accel == T3D_ACCEL_AUTO && n_prims > T3D_BRUTE_FORCE_MAX_PRIMS));
+    if (!want_bvh && s->n_tris >= (1 << 26)) { c->err = "t3d_upload_scene: too many triangles for the brute-force path"; return T3D_E_CAPACITY; }
     int n_owned = 0;
     for (int o = 0; o < s->n_objects; ++o) {
         obj_ior[o] = (float)s->obj_ior[o];
@@ -2186,7 +2193,8 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
             // rows are stored (x, offset, y, z): the first fma of a dot product then takes its factor and its
             // addend from one aligned SGPR pair; "+ 0.0f" turns a -0 offset into +0
             planes[6 * g] = make_float4((float)F.n[0], -(float)F.nv0 + 0.0f, (float)F.n[1], (float)F.n[2]);
-            planes[6 * g + 1] = make_float4(__builtin_bit_cast(float, k), __builtin_bit_cast(float, k + pc.count), 0.f, 0.f);
+            planes[6 * g + 1] = make_float4(__builtin_bit_cast(float, k), __builtin_bit_cast(float, k + pc.count), 0.f,
+                                            __builtin_bit_cast(float, k | (pc.count << 26)));
             plane_first[g] = k;
             const int i1 = (pc.axis + 1) % 3, i2 = (pc.axis + 2) % 3;  // in-plane coordinates (s, t)
             for (int j = 0; j < pc.count; ++j) {
@@ -2260,7 +2268,7 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
                                (float)s->shader_rough[k], (float)s->shader_refl[k], (float)s->shader_emis[k], 0.f, 0.f};
     }
     std::vector<DevLight> lights = make_lights(c->sc, s);
-    std::vector<float4> prim_info(3 * ((size_t)s->n_tris + spheres.size()));
+    std::vector<float4> prim_info(4 * ((size_t)s->n_tris + spheres.size()));
     {
         auto ib = [](int v) { return __builtin_bit_cast(float, v); };
         for (int k = 0; k < s->n_tris; ++k) {
@@ -2271,12 +2279,13 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
                 const Tri& T = tris[order[k]];
                 const double len = sqrt(T.n[0] * T.n[0] + T.n[1] * T.n[1] + T.n[2] * T.n[2]);
                 const double inv = len > 0 ? 1.0 / len : 0.0;
-                prim_info[3 * (size_t)k + 0] = make_float4((float)(T.n[0] * inv), (float)(T.n[1] * inv), (float)(T.n[2] * inv), obj_ior[m.x]);
+                prim_info[4 * (size_t)k + 0] = make_float4((float)(T.n[0] * inv), (float)(T.n[1] * inv), (float)(T.n[2] * inv), obj_ior[m.x]);
             }
-            prim_info[3 * (size_t)k + 1] = make_float4(ib(m.x), ib(m.y), ib(m.z), ib(emitter ? 1 : 0));
-            prim_info[3 * (size_t)k + 2] = make_float4(sh.rough, sh.refl, sh.emis, emitter ? 1.0f : 1.0f - sh.refl);
+            prim_info[4 * (size_t)k + 1] = make_float4(ib(m.x), ib(m.y), ib(m.z), ib(emitter ? 1 : 0));
+            prim_info[4 * (size_t)k + 2] = make_float4(sh.rough, sh.refl, sh.emis, emitter ? 1.0f : 1.0f - sh.refl);
+            prim_info[4 * (size_t)k + 3] = make_float4(sh.r, sh.g, sh.b, 0.f);
         }
-        for (size_t q = 0; q < spheres.size(); ++q) sphere_rows(spheres[q], s, &prim_info[3 * ((size_t)s->n_tris + q)]);
+        for (size_t q = 0; q < spheres.size(); ++q) sphere_rows(spheres[q], s, &prim_info[4 * ((size_t)s->n_tris + q)]);
     }
     int rc;
     if ((rc = upload(c, &c->d_prim_info, prim_info)) || (rc = upload(c, &c->d_planes, planes)) || (rc = upload(c, &c->d_plane_first, plane_first)) || (rc = upload(c, &c->d_tri_uv, tri_uv)) ||
@@ -2364,20 +2373,20 @@ extern "C" int t3d_update_scene(t3d_ctx* c, const t3d_scene_desc* s) {
     // (the stream is idle now: the staging vectors of the previous update are free again)
     std::vector<DevSphere>& spheres = c->h_spheres;
     std::vector<float4>& rows = c->up_rows;
-    rows.resize(3 * spheres.size());
+    rows.resize(4 * spheres.size());
     for (size_t q = 0; q < spheres.size(); ++q) {
         DevSphere& sp = spheres[q];
         const int o = sp.obj;
         sp.cx = (float)s->obj_center[3 * o]; sp.cy = (float)s->obj_center[3 * o + 1]; sp.cz = (float)s->obj_center[3 * o + 2];
         sp.r2 = (float)(s->obj_radius[o] * s->obj_radius[o]);
         sp.strength = (float)s->obj_strength[o];
-        sphere_rows(sp, s, &rows[3 * q]);
+        sphere_rows(sp, s, &rows[4 * q]);
     }
     c->up_light_rows = make_lights(c->sc, s);
     const std::vector<DevLight>& lights = c->up_light_rows;
     if (!spheres.empty()) {
         HIPCHK(c, hipMemcpyAsync(c->d_spheres, spheres.data(), sizeof(DevSphere) * spheres.size(), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync((float4*)c->d_prim_info + 3 * (size_t)c->up_tris, rows.data(), sizeof(float4) * rows.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync((float4*)c->d_prim_info + 4 * (size_t)c->up_tris, rows.data(), sizeof(float4) * rows.size(), hipMemcpyHostToDevice, c->stream));
     }
     if (!lights.empty()) HIPCHK(c, hipMemcpyAsync(c->d_lights, lights.data(), sizeof(DevLight) * lights.size(), hipMemcpyHostToDevice, c->stream));
     set_scene_box(c, spheres);
