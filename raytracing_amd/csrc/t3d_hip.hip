@@ -817,9 +817,18 @@ __device__ __forceinline__ void transmit_side(const Outcome& r, const RayIn& in,
 // may_spawn: the ray's level is below options['bounces'] (T3DR.py:976-977)
 // ONE: the launch may be the tree of a single ray (t3d_trace_pixel / t3d_trace_ray); kernels that only ever trace image
 // bands say so, and the parameters of that mode are not kept in registers
+// The record of the primitive a ray hit (DevScene::prim_info).  Fetched for every lane, hit or not (a miss reads record 0 and
+// ignores it), so that the requests of a lane's rays are not tied to the rays' own outcomes and can all be in flight
+// before the first of them is classified.
+struct PrimRows { float4 i0, i1, i2, i3; };
+__device__ __forceinline__ PrimRows fetch_prim_rows(const DevScene& sc, const Hit& h) {
+    const float4* __restrict__ info = sc.prim_info + 4 * (size_t)(h.prim > 0 ? h.prim : 0);
+    return PrimRows{info[0], info[1], info[2], info[3]};
+}
+
 template <bool ONE = true>
-__device__ __forceinline__ Outcome hit_outcome(const DevScene& sc, const RenderParams& rp,
-                                               const RayIn& in, const Hit& h, bool level0, bool may_spawn, const TraceOut& out) {
+__device__ __forceinline__ Outcome hit_outcome(const DevScene& sc, const RenderParams& rp, const RayIn& in, const Hit& h, const PrimRows& pr,
+                                               bool level0, bool may_spawn, const TraceOut& out) {
     const int single = ONE ? rp.single : 0;
     Outcome r;
     const V3 o = in.o, d = in.d;
@@ -834,9 +843,7 @@ __device__ __forceinline__ Outcome hit_outcome(const DevScene& sc, const RenderP
     float strength = 1.0f, refl = 1.0f;
     r.rough = 1.0f; r.obj_ior = 1.0f;
     if (r.hit) {
-        const float4* __restrict__ info = sc.prim_info + 4 * (size_t)h.prim;
-        const float4 i0 = info[0], i1 = info[1], i2 = info[2], i3 = info[3];
-        asm volatile("" :: "v"(i3.x));   // all four rows in flight together: an emitter's colour is not fetched behind the test for one
+        const float4 i0 = pr.i0, i1 = pr.i1, i2 = pr.i2, i3 = pr.i3;
         const int kind = __float_as_int(i1.w);
         r.obj = __float_as_int(i1.x); r.face = __float_as_int(i1.y); r.shader = __float_as_int(i1.z);
         if (!(kind & 2)) {
@@ -946,8 +953,11 @@ __device__ __forceinline__ void process_rays(const DevScene& sc, const DevLight*
                                              float4* ring_b, int& ring_nodes, PairList* pl = nullptr) {
     const bool want_debug = ONE && rp.want_debug;
     Outcome oc[NR];
+    PrimRows rows[NR];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) oc[r] = hit_outcome<ONE>(sc, rp, in[r], h[r], LEVEL0, wc.level < rp.bounces, out);
+    for (int r = 0; r < NR; ++r) rows[r] = fetch_prim_rows(sc, h[r]);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) oc[r] = hit_outcome<ONE>(sc, rp, in[r], h[r], rows[r], LEVEL0, wc.level < rp.bounces, out);
 
     // ---- debug records (single-pixel mode) ----------------------------------------------
     int dbg_idx[NR];
@@ -1108,13 +1118,29 @@ __device__ __forceinline__ void process_rays(const DevScene& sc, const DevLight*
 
 template <bool LEVEL0, bool ONE = true>
 __device__ __forceinline__ void load_ray(const DevScene& sc, const RenderParams& rp, const RayRec* __restrict__ rays_in,
-                                         int idx, int n_in, int queue_base, RayIn& in) {
+                                         int idx, int n_in, int queue_base, RayIn& in, const RayRec* fetched = nullptr) {
     const int single = ONE ? rp.single : 0;
     in.active = idx < n_in;
     in.i = LEVEL0 ? idx : queue_base + idx;
     in.o = mk(0, 0, 0); in.d = mk(0, 0, 1); in.pstart = mk(0, 0, 0);
     in.ior = 1.0f; in.inside_obj = -1; in.parent = -1; in.side = 0;
     in.ps = 0; in.heap = 1; in.pixel_hash = 0; in.px = 0; in.py = 0; in.smp = 0;
+    if constexpr (!LEVEL0) {
+        // The record is fetched by every lane (a lane without a ray reads the first entry of the shard's queue and ignores
+        // it): the requests of a lane's two rays are then not tied to the rays' own conditions and are all in flight together.
+        // (`fetched`: the caller has done that already, see k_level)
+        const RayRec r = fetched ? *fetched : rays_in[in.active ? in.i : queue_base];
+        if (in.active) {
+            in.o = mk(r.o.x, r.o.y, r.o.z); in.ior = r.o.w;
+            in.d = mk(r.d.x, r.d.y, r.d.z); in.inside_obj = __float_as_int(r.d.w);
+            in.pstart = mk(r.p.x, r.p.y, r.p.z); in.parent = __float_as_int(r.p.w);
+            // a level that overflowed its queue (the frame is then traced again with more room) may hand on entries
+            // that nobody wrote: whatever they hold, the parent they name stays inside the node arrays
+            in.parent = min(max(in.parent, 0), (rp.bounces + 1) * rp.cap - 1);
+            in.ps = r.k.x; in.heap = r.k.y; in.side = (int)r.k.z; in.pixel_hash = r.k.w;
+        }
+        return;
+    }
     if (in.active) {
         if (LEVEL0) {
             if (rp.tiled) {
@@ -1143,15 +1169,6 @@ __device__ __forceinline__ void load_ray(const DevScene& sc, const RenderParams&
             } else {
                 camera_ray(sc.cam, rp, in.px, in.py, in.o, in.d);
             }
-        } else {
-            RayRec r = rays_in[in.i];
-            in.o = mk(r.o.x, r.o.y, r.o.z); in.ior = r.o.w;
-            in.d = mk(r.d.x, r.d.y, r.d.z); in.inside_obj = __float_as_int(r.d.w);
-            in.pstart = mk(r.p.x, r.p.y, r.p.z); in.parent = __float_as_int(r.p.w);
-            // a level that overflowed its queue (the frame is then traced again with more room) may hand on entries
-            // that nobody wrote: whatever they hold, the parent they name stays inside the node arrays
-            in.parent = min(max(in.parent, 0), (rp.bounces + 1) * rp.cap - 1);
-            in.ps = r.k.x; in.heap = r.k.y; in.side = (int)r.k.z; in.pixel_hash = r.k.w;
         }
     }
 }
@@ -1273,8 +1290,18 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_level(DevScene sc, GEO_PARAMS
 #endif
             // ---------------- trace round: rays chunk*cs + lane and (cs = 128) chunk*cs + 64 + lane ----------------
             RayIn in[2];
-            load_ray<LEVEL0, ONE>(sc, rp, rays_in, chunk * cs + wc.lane, wc.lane < cs ? n_in : 0, queue_base, in[0]);
-            load_ray<LEVEL0, ONE>(sc, rp, rays_in, chunk * cs + 64 + wc.lane, cs == 128 ? n_in : 0, queue_base, in[1]);
+            if constexpr (LEVEL0) {
+                load_ray<LEVEL0, ONE>(sc, rp, rays_in, chunk * cs + wc.lane, wc.lane < cs ? n_in : 0, queue_base, in[0]);
+                load_ray<LEVEL0, ONE>(sc, rp, rays_in, chunk * cs + 64 + wc.lane, cs == 128 ? n_in : 0, queue_base, in[1]);
+            } else {
+                // both records of the lane are requested before either is looked at (a lane without a ray reads the first
+                // entry of its shard's queue and ignores it)
+                const int i0 = chunk * cs + wc.lane, i1 = i0 + 64, n0 = wc.lane < cs ? n_in : 0, n1 = cs == 128 ? n_in : 0;
+                const RayRec q0 = rays_in[queue_base + (i0 < n0 ? i0 : 0)], q1 = rays_in[queue_base + (i1 < n1 ? i1 : 0)];
+                asm volatile("" :: "v"(q0.o.x), "v"(q0.d.x), "v"(q0.p.x), "v"(q0.k.x), "v"(q1.o.x), "v"(q1.d.x), "v"(q1.p.x), "v"(q1.k.x));
+                load_ray<LEVEL0, ONE>(sc, rp, rays_in, i0, n0, queue_base, in[0], &q0);
+                load_ray<LEVEL0, ONE>(sc, rp, rays_in, i1, n1, queue_base, in[1], &q1);
+            }
             const bool lights = LEVEL0 ? (rp.lights != 0) : true;
             Hit h[2];  // back faces culled iff ray.ior == 1 (T3DR.py:961)
             closest_hit2<LEVEL0>(GEO_ARGS, sc.geo, in[0].o, in[0].d, in[1].o, in[1].d, lights, in[0].ior == 1.0f, in[1].ior == 1.0f, h[0], h[1], gcp_t);
@@ -2268,7 +2295,7 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
                                (float)s->shader_rough[k], (float)s->shader_refl[k], (float)s->shader_emis[k], 0.f, 0.f};
     }
     std::vector<DevLight> lights = make_lights(c->sc, s);
-    std::vector<float4> prim_info(4 * ((size_t)s->n_tris + spheres.size()));
+    std::vector<float4> prim_info(4 * std::max<size_t>(1, (size_t)s->n_tris + spheres.size()), make_float4(0.f, 0.f, 0.f, 0.f));   // never empty: a miss reads record 0
     {
         auto ib = [](int v) { return __builtin_bit_cast(float, v); };
         for (int k = 0; k < s->n_tris; ++k) {
