@@ -954,8 +954,11 @@ __device__ __forceinline__ void process_rays(const DevScene& sc, const DevLight*
     const bool want_debug = ONE && rp.want_debug;
     Outcome oc[NR];
     PrimRows rows[NR];
+    bool any_hit = false;   // wave-uniform: a round of camera rays that all leave the scene (two in five on the benchmark frame) fetches and tests nothing
 #pragma unroll
-    for (int r = 0; r < NR; ++r) rows[r] = fetch_prim_rows(sc, h[r]);
+    for (int r = 0; r < NR; ++r) any_hit |= __any((int)(in[r].active && h[r].prim >= 0)) != 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) rows[r] = any_hit ? fetch_prim_rows(sc, h[r]) : PrimRows{};
 #pragma unroll
     for (int r = 0; r < NR; ++r) oc[r] = hit_outcome<ONE>(sc, rp, in[r], h[r], rows[r], LEVEL0, wc.level < rp.bounces, out);
 
@@ -1025,7 +1028,7 @@ __device__ __forceinline__ void process_rays(const DevScene& sc, const DevLight*
             const V3 V = mk(sc.cam.pos[0] - oc[r].P.x, sc.cam.pos[1] - oc[r].P.y, sc.cam.pos[2] - oc[r].P.z);
             const float vv = dot(V, V);
             pair_pos[r] = pairs_total;
-            for (int l = 0; l < wc.L; ++l) {
+            for (int l = 0; any_hit && l < wc.L; ++l) {
                 // lights: the light array as a kernel argument of its own, so that this wave-uniform read goes through the
                 // scalar cache (through the pointer in the scene structure it would be a vector load, waited for per light)
                 const bool lv = oc[r].shaded && !light_dead(lights[l], oc[r].P, oc[r].N, V, vv, oc[r].rough);
