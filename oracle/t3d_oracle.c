@@ -397,6 +397,13 @@ static void first_collision_faces(Ctx* c, const Ray* ray, int o, const int* face
         int t = faces[i];
         Hit h = face_collision(c, ray, tri_v(s, t, 0), tri_v(s, t, 1), tri_v(s, t, 2));
         if (h.hit && (h.direction == 0 || !backCull)) {
+            /* fragility (test aid): two surfaces met at all but the same distance -- the ray runs through the line in which
+             * two faces cross -- may change places in another precision, like a ray on a triangle's edge */
+            if (best->obj >= 0) {
+                double near = h.t < best->t ? h.t : best->t;
+                double m = fabs(h.t - best->t) / (near > 1 ? near : 1);
+                if (m > 0 && m < c->frag) c->frag = m;   /* (faces that coincide tie exactly in every precision) */
+            }
             if (best->obj < 0 || h.t < best->t) {
                 best->obj = o; best->point = h.point; best->t = h.t; best->normal = h.normal;
                 best->direction = h.direction; best->face = t;
@@ -430,6 +437,11 @@ static Collision first_collision(Ctx* c, const Ray* ray, int lights, int backCul
             c->st.sphere_tests++;
             V3 ctr = v3(s->obj_center[3 * o], s->obj_center[3 * o + 1], s->obj_center[3 * o + 2]);
             Hit h = sphere_collision(c, ray, ctr, s->obj_radius[o], ty == T3D_OBJ_LIGHT, backCull);
+            if (h.hit && best.obj >= 0) {   /* fragility: see first_collision_faces */
+                double near = h.t < best.t ? h.t : best.t;
+                double m = fabs(h.t - best.t) / (near > 1 ? near : 1);
+                if (m > 0 && m < c->frag) c->frag = m;   /* (faces that coincide tie exactly in every precision) */
+            }
             if (h.hit && (best.obj < 0 || h.t < best.t)) {
                 best.obj = o; best.point = h.point; best.t = h.t; best.normal = h.normal;
                 best.direction = h.direction;
