@@ -98,7 +98,7 @@ struct DevCamera {
 //                     bits, a parallelogram flag and the range once more as first | count << 26 (what a ray keeps of the
 //                     group it hit); the tri_uv rows of its first two triangles (zeros where the
 //                     group has only one; for a parallelogram only the first triangle's, see t3d_upload_scene)
-//   plane_first [G+1] triangle range of each group
+//   plane_first [G+1] triangle range of each group (no kernel reads it any more: a group's range comes with its record)
 //   tri_uv      [2T]  per triangle (a_s, aw, a_t, 0), (b_s, bw, b_t, 0): barycentric rows in the two in-plane
 //                     coordinates (s, t) left after dropping the group's dominant axis, prepared in float64
 #define GEO_PARAMS const float4* __restrict__ planes, const int* __restrict__ plane_first, \
