@@ -6,8 +6,8 @@ r=$1; tag=$2; pmc=$3
 G=gpurun_out; P=profiles
 commit=$(git log --oneline | head -1 | cut -d' ' -f1)
 sed -n '/^== default command/,$p' $G/${tag}_profile.log | grep -v "^prof_" > $P/${r}_bench_kernel_trace_summary.txt
-cp $G/prof_${tag}/*/*_kernel_stats.csv $P/${r}_bench_kernel_stats.csv
-cp $G/prof_${tag}_solo/*/*_kernel_stats.csv $P/${r}_bench_solo_kernel_stats.csv
+cp "$(ls -t $G/prof_${tag}/*/*_kernel_stats.csv | head -1)" $P/${r}_bench_kernel_stats.csv   # (the newest run of that tag)
+cp "$(ls -t $G/prof_${tag}_solo/*/*_kernel_stats.csv | head -1)" $P/${r}_bench_solo_kernel_stats.csv
 cp $G/prof_${tag}_bench.json $P/${r}_bench_under_rocprof.json
 cp $G/prof_${tag}_solo_bench.json $P/${r}_bench_solo_under_rocprof.json
 cp $G/${tag}_bench_default.json $P/${r}_bench_default.json
