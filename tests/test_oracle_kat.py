@@ -145,3 +145,31 @@ def test_keyed_rng_python_equals_c(oracle_mod):
         seed, px, py = int(rng.integers(0, 2**32)), int(rng.integers(0, 8192)), int(rng.integers(0, 8192))
         sample, heap, comp = int(rng.integers(0, 64)), int(rng.integers(1, 1024)), int(rng.integers(0, 3))
         assert keyed_rng.keyed_bits24(seed, px, py, sample, heap, comp) == lib.t3do_keyed_bits24(seed, px, py, sample, heap, comp)
+
+
+def test_fragility_of_crossing_faces(oracle_mod):
+    """Test aid, not reference behaviour: a primary ray that meets two faces at all but the same distance (it runs past
+    the line in which they cross) is reported as fragile, as a ray on a triangle's edge is; faces that coincide tie exactly
+    in every precision and are not."""
+    from raytracing_amd.scene import Camera, Mesh, Object, Shader
+
+    def scene_of(tris):
+        s = Scene()
+        Camera(s, position=Vec3(0.001, 0, -5), length=50)
+        verts = [Vec3(*p) for t in tris for p in t]
+        o = Object(scene=s, name="faces", mesh=Mesh(verts, [(3 * k, 3 * k + 2, 3 * k + 1) for k in range(len(tris))]))   # facing the camera
+        o.setShader(Shader(color=RGB(200, 200, 200), roughness=1.0, reflectivity=1.0))
+        return flatten_scene(s)
+
+    # two triangles far larger than the view, in the planes z = 3 + 0.1 x and z = 3 - 0.1 x: they cross in the line x = 0
+    a = [(-50, -50, -2), (50, -50, 8), (0, 80, 3)]
+    b = [(-50, -50, 8), (50, -50, -2), (0, 80, 3)]
+    opt = dict(width=64, height=8, bounces=0)
+    flat = scene_of([a, b])
+    ids = oracle_mod.render(flat, opt)["prim"][:, :, 1]
+    assert (ids[:, :30] == 0).all() and (ids[:, 34:] == 1).all()       # the nearer face on either side of the line
+    frag = oracle_mod.primary_fragility(flat, opt)
+    assert frag[:, 31:33].min() < 2e-4 and frag[:, :24].min() > 1e-3 and frag[:, 40:].min() > 1e-3
+    # the same face twice: equal distances everywhere, nothing fragile about it
+    frag2 = oracle_mod.primary_fragility(scene_of([a, a]), opt)
+    assert frag2.min() > 1e-3
