@@ -47,7 +47,7 @@ def source_digest():
     """Fingerprint of the tracing kernels' sources: says which build a counter run belongs to (there is no git on the GPU box)."""
     import hashlib
     h = hashlib.sha1()
-    for name in ("t3d_hip.hip", "t3d_lbvh.h"):
+    for name in ("t3d_hip.hip", "t3d_lbvh.h", "t3d_host_tree.h"):
         with open(os.path.join(ROOT, "raytracing_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:12]

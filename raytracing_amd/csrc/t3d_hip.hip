@@ -474,6 +474,9 @@ __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0
 #define T3D_BVH_LDS_STACK 24   // entries per lane in LDS: 4 waves x 24 x 64 lanes x 4 B = 24 KB per block, 6 blocks per CU
 #endif
 #define T3D_BVH_DEEP_STACK (T3D_BVH_STACK - T3D_BVH_LDS_STACK)
+#ifndef T3D_HOST_TREE_MAX_PRIMS
+#define T3D_HOST_TREE_MAX_PRIMS 16384   // scenes up to this size get the host-built hierarchy (about 5 ms of host time at the limit)
+#endif
 #ifndef T3D_BVH_WAVES
 #define T3D_BVH_WAVES 6   // waves per SIMD the traversal kernels are compiled for
 #endif
@@ -2345,8 +2348,34 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
         if ((rc = upload(c, &d_tri_ab, tri_ab)) || (rc = upload(c, &d_verts, verts))) { hipFree(d_verts); hipFree(d_tri_ab); return rc; }
         float4* nodes = nullptr;
         float4* leaves = nullptr;
+        // Few primitives: the hierarchy is built here, top-down by surface area (t3d_host_tree.h), at about 0.3 us a primitive;
+        // many: in Morton order on the device, which takes a tenth of that and gives a tree some 5 % (uniform soup) to 15 %
+        // (a mesh in a room) slower to traverse.  T3D_HOST_TREE_MAX moves the line (0: always on the device): worth raising
+        // for a scene that is rendered many times.
+        HostTree host_tree;
+        const char* env_max = getenv("T3D_HOST_TREE_MAX");
+        const long host_max = env_max ? atol(env_max) : T3D_HOST_TREE_MAX_PRIMS;
+        bool host_built = n_prims >= 2 && n_prims <= host_max;
+        if (host_built) {
+            std::vector<float> blo(3 * (size_t)n_prims), bhi(3 * (size_t)n_prims);
+            for (int k = 0; k < s->n_tris; ++k)
+                for (int a = 0; a < 3; ++a) {
+                    const float* v = &verts[9 * (size_t)k];
+                    blo[3 * (size_t)k + a] = fminf(fminf(v[a], v[3 + a]), v[6 + a]);
+                    bhi[3 * (size_t)k + a] = fmaxf(fmaxf(v[a], v[3 + a]), v[6 + a]);
+                }
+            for (size_t q = 0; q < spheres.size(); ++q) {
+                const DevSphere& sp = spheres[q];
+                const float r = sqrtf(sp.r2), ce[3] = {sp.cx, sp.cy, sp.cz};
+                for (int a = 0; a < 3; ++a) { blo[3 * (s->n_tris + q) + a] = ce[a] - r; bhi[3 * (s->n_tris + q) + a] = ce[a] + r; }
+            }
+            host_tree = host_tree_build(blo.data(), bhi.data(), n_prims);
+            // a surface-area tree has no bound on its depth (sizes in geometric progression give a chain); the traversal
+            // stack is sized for the Morton tree's (30 key bits + ties): deeper than that, take the Morton tree
+            host_built = host_tree.depth <= T3D_BVH_STACK / 2;
+        }
         hipError_t e = lbvh_build(c->stream, (const float*)d_verts, (const float4*)d_tri_ab, s->n_tris, (const DevSphere*)c->d_spheres,
-                                  (int)spheres.size(), &nodes, &leaves, &c->lbvh_work);
+                                  (int)spheres.size(), &nodes, &leaves, &c->lbvh_work, host_built ? &host_tree : nullptr);
         if (e != hipSuccess) { hipFree(d_verts); hipFree(d_tri_ab); c->err = std::string("t3d_upload_scene: LBVH build failed: ") + hipGetErrorString(e); return T3D_E_DEVICE; }
         c->d_lbvh_verts = d_verts; c->d_lbvh_tri_ab = d_tri_ab;   // kept for a refit (t3d_update_scene)
         c->d_bvh_nodes = nodes; c->d_bvh_leaves = leaves;

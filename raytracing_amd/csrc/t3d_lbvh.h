@@ -10,6 +10,7 @@
 //
 // Included by t3d_hip.hip (one translation unit, one shared library).
 #pragma once
+#include "t3d_host_tree.h"
 
 #define LBVH_BLOCK 256
 
@@ -326,8 +327,9 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_leaves(const int* __restric
 // intersection records in the same order) and n_spheres spheres; *out_nodes receives n - 1 traversal nodes and
 // *out_leaves n leaf records of 64 bytes each (hipMalloc, owned by the caller).  Needs n >= 2.
 // `keep`: where the build's working arrays go instead of being released, for lbvh_refit.
+// host: a hierarchy to use instead of the Morton-order one (null: build that one here)
 static hipError_t lbvh_build(hipStream_t st, const float* d_verts, const float4* d_tri_ab, int n_tris, const DevSphere* d_spheres,
-                             int n_spheres, float4** out_nodes, float4** out_leaves, LbvhWork* keep = nullptr) {
+                             int n_spheres, float4** out_nodes, float4** out_leaves, LbvhWork* keep = nullptr, const HostTree* host = nullptr) {
     const int n = n_tris + n_spheres;
     LbvhWork w;
     hipError_t e = hipSuccess;
@@ -352,9 +354,15 @@ static hipError_t lbvh_build(hipStream_t st, const float* d_verts, const float4*
     int nb = (n + LBVH_BLOCK - 1) / LBVH_BLOCK;
     hipLaunchKernelGGL(k_lbvh_bounds, dim3((unsigned)(nb > 1024 ? 1024 : nb)), dim3(LBVH_BLOCK), 0, st, d_verts, n_tris, d_spheres, n_spheres,
                        w.prim_lo, w.prim_hi, w.bounds);
-    hipLaunchKernelGGL(k_lbvh_morton, blocks(n), dim3(LBVH_BLOCK), 0, st, w.prim_lo, w.prim_hi, n, w.bounds, w.keys[0], w.vals[0]);
     int cur = 0;
-    for (int shift = 0; shift < 32; shift += 8) {
+    if (host) {
+        LB(hipMemcpyAsync(w.vals[0], host->order.data(), sizeof(int) * n, hipMemcpyHostToDevice, st));
+        LB(hipMemcpyAsync(w.kids, host->kids.data(), sizeof(HostTreeKids) * (n - 1), hipMemcpyHostToDevice, st));
+        LB(hipMemcpyAsync(w.parent, host->parent.data(), sizeof(int) * (2 * (size_t)n - 1), hipMemcpyHostToDevice, st));
+        LB(hipStreamSynchronize(st));   // the caller's vectors may go
+    } else
+    hipLaunchKernelGGL(k_lbvh_morton, blocks(n), dim3(LBVH_BLOCK), 0, st, w.prim_lo, w.prim_hi, n, w.bounds, w.keys[0], w.vals[0]);
+    for (int shift = 0; !host && shift < 32; shift += 8) {
         LB(hipMemsetAsync(w.hist, 0, sizeof(int) * 256 * (size_t)nt, st));
         hipLaunchKernelGGL(k_lbvh_rs_count, blocks(nt), dim3(LBVH_BLOCK), 0, st, w.keys[cur], n, shift, chunk, nt, w.hist);
         const int m = 256 * nt, n_tiles = (m + LBVH_SCAN_TILE - 1) / LBVH_SCAN_TILE;   // nt <= 16384: at most 1024 tiles
@@ -366,7 +374,7 @@ static hipError_t lbvh_build(hipStream_t st, const float* d_verts, const float4*
         cur ^= 1;
     }
     LB(hipMemsetAsync(w.flags, 0, sizeof(int) * (n - 1), st));
-    hipLaunchKernelGGL(k_lbvh_hierarchy, blocks(n - 1), dim3(LBVH_BLOCK), 0, st, w.keys[cur], n, w.kids, w.parent);
+    if (!host) hipLaunchKernelGGL(k_lbvh_hierarchy, blocks(n - 1), dim3(LBVH_BLOCK), 0, st, w.keys[cur], n, w.kids, w.parent);
     hipLaunchKernelGGL(k_lbvh_refit, blocks(n), dim3(LBVH_BLOCK), 0, st, w.vals[cur], n, w.prim_lo, w.prim_hi, w.kids, w.parent, w.box_lo,
                        w.box_hi, w.flags);
     hipLaunchKernelGGL(k_lbvh_pack, blocks(n - 1), dim3(LBVH_BLOCK), 0, st, w.vals[cur], n, w.prim_lo, w.prim_hi, w.kids, w.box_lo, w.box_hi,

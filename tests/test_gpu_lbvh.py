@@ -1,4 +1,4 @@
-"""The device-built LBVH path (large scenes) against the CPU oracle and against the brute-force path.
+"""The LBVH path (large scenes; tree built on the device, or on the host for small ones) against the CPU oracle and against the brute-force path.
 
 The hierarchy is a conservative cull, as the reference's own BVH is (T3DR.py:553-569, 659-707): the closest
 hit it finds must be the brute-force closest hit, so every tolerance of test_gpu_parity.py applies unchanged.
@@ -155,6 +155,64 @@ def test_lbvh_agrees_with_brute_force_on_the_gpu(gpu_ctx, lbvh_ctx):
     assert same_ids.mean() >= 0.9995            # the two paths round the interior test differently on edges
     assert abs(brute["stats"]["queries"] - fast["stats"]["queries"]) <= 1e-3 * brute["stats"]["queries"]
     assert fast["stats"]["tri_tests"] < 0.05 * brute["stats"]["tri_tests"]
+
+
+def test_host_built_and_device_built_trees_give_the_same_picture(lbvh_ctx, monkeypatch):
+    """Scenes of up to some thousand primitives get a hierarchy built on the host by surface area, larger ones the
+    Morton-order one built on the device (T3D_HOST_TREE_MAX moves the line).  Either is only a cull: pixels, ids and
+    distances must be the same bit for bit; the number of boxes tested is what differs."""
+    flat = _soup(3000, 20, 150)
+    opt = dict(width=160, height=90, bounces=2, samples=1)
+    monkeypatch.setenv("T3D_HOST_TREE_MAX", "0")
+    lbvh_ctx.upload(flat)
+    dev = lbvh_ctx.render_rows(opt, seed=9, want_radiance=True, want_primary=True)
+    monkeypatch.setenv("T3D_HOST_TREE_MAX", "1000000")
+    lbvh_ctx.upload(flat)
+    host = lbvh_ctx.render_rows(opt, seed=9, want_radiance=True, want_primary=True)
+    for key in ("bgr", "radiance", "prim", "prim_t"):
+        assert np.array_equal(dev[key], host[key], equal_nan=dev[key].dtype.kind == "f"), key   # prim_t: NaN where nothing is hit
+    assert dev["stats"]["queries"] == host["stats"]["queries"] and dev["stats"]["shadow_queries"] == host["stats"]["shadow_queries"]
+    assert host["stats"]["aabb_tests"] != dev["stats"]["aabb_tests"]          # two different trees were traversed
+    assert host["stats"]["aabb_tests"] < 1.02 * dev["stats"]["aabb_tests"]    # and the host's is no worse
+    # spheres and the camera moved: the refit keeps whichever tree was built
+    from dataclasses import replace
+    from raytracing_amd.flatten import OBJ_SPHERE
+    centre = flat.obj_center.copy()
+    centre[flat.obj_type == OBJ_SPHERE] += np.array([0.05, -0.02, 0.03])
+    moved = replace(flat, obj_center=centre, signature_digest=None)
+    lbvh_ctx.update(moved)
+    refit = lbvh_ctx.render_rows(opt, seed=9, want_primary=True)
+    lbvh_ctx.upload(moved)
+    rebuilt = lbvh_ctx.render_rows(opt, seed=9, want_primary=True)
+    assert np.array_equal(refit["bgr"], rebuilt["bgr"]) and np.array_equal(refit["prim"], rebuilt["prim"])
+
+
+def test_too_deep_a_host_tree_is_not_used(lbvh_ctx, monkeypatch):
+    """Triangles whose sizes fall off geometrically over 27 decades, 8 coincident copies of each: the surface-area build
+    peels the large ones off a few per level and ends 52 levels deep, more than the traversal stack is sized for; the
+    library notices and takes the Morton-order tree (same box count as with the host build switched off)."""
+    from dataclasses import replace
+    from raytracing_amd.workloads import synthetic_flat
+    n = 8000
+    base = synthetic_flat(n_random_tris=4, grid=1, n_spheres=2, seed=1, extent=12.0, camera=(0.3713, 0.2117, -28.8))
+    s = 10.0 * (15.0 / 16.0) ** (np.arange(n) % 1000)
+    c = np.stack([s, s, s], 1)
+    tri = np.empty((n, 3, 3))
+    tri[:, 0] = c + np.stack([-0.4 * s, -0.4 * s, 0 * s], 1)
+    tri[:, 1] = c + np.stack([0 * s, 0.4 * s, 0.1 * s], 1)
+    tri[:, 2] = c + np.stack([0.4 * s, -0.4 * s, -0.1 * s], 1)
+    count = base.obj_tri_count.copy()
+    count[0] = n
+    flat = replace(base, tri_verts=np.ascontiguousarray(tri), tri_shader=np.full(n, 3, np.int32), obj_tri_count=count)
+    opt = dict(width=96, height=54, bounces=1, samples=1)
+    monkeypatch.setenv("T3D_HOST_TREE_MAX", "0")
+    lbvh_ctx.upload(flat)
+    dev = lbvh_ctx.render_rows(opt, seed=2, want_primary=True)
+    monkeypatch.delenv("T3D_HOST_TREE_MAX")
+    lbvh_ctx.upload(flat)
+    auto = lbvh_ctx.render_rows(opt, seed=2, want_primary=True)
+    assert np.array_equal(dev["bgr"], auto["bgr"]) and np.array_equal(dev["prim"], auto["prim"])
+    assert dev["stats"]["aabb_tests"] == auto["stats"]["aabb_tests"]
 
 
 def test_closest_hits_through_lbvh(lbvh_ctx, oracle_mod):
