@@ -178,7 +178,7 @@ def main():
     # buffer; trace, then gather, on that stream) with nothing that orders one chain against another.  Every step is
     # still one complete frame, traced and gathered, and every frame of the run is a different one: frame g has seed g
     # (--fixed-seed: every call starts again at seed 0).
-    lbvh_scene = args.accel == "lbvh" or (args.accel == "auto" and flat.n_tris + flat.n_spheres > 256)
+    lbvh_scene = args.accel == "lbvh" or (args.accel == "auto" and flat.n_tris + flat.n_spheres > _native.BRUTE_FORCE_MAX_PRIMS)
     # one rank's share of a frame is a chain of small launches: more of them in flight, and full rounds (no slot of a
     # round wasted; the other chains hide the latency the adaptive cut is there to shorten)
     # (four: one chain per hardware queue of the process; a fifth shares a queue and costs 9 %, three leave 2.5 % unused)

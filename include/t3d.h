@@ -353,7 +353,7 @@ int t3d_set_rounds(t3d_ctx* ctx, int mode);
  * hierarchy is a conservative cull and the hit found is the brute-force closest hit.
  */
 enum { T3D_ACCEL_AUTO = 0, T3D_ACCEL_BRUTE_FORCE = 1, T3D_ACCEL_LBVH = 2 };
-#define T3D_BRUTE_FORCE_MAX_PRIMS 256
+#define T3D_BRUTE_FORCE_MAX_PRIMS 176   /* where the two meet in a closed room; in a sparse scene the LBVH is ahead from 80 on */
 int t3d_set_accel(t3d_ctx* ctx, int mode);
 
 /*

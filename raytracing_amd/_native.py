@@ -13,6 +13,7 @@ from .flatten import FlatScene, Opts, SceneDesc, Stats, make_opts
 
 LIB_PATH = os.environ.get("T3D_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libt3d_hip.so")
 ABI_VERSION = 7
+BRUTE_FORCE_MAX_PRIMS = 176   # T3D_BRUTE_FORCE_MAX_PRIMS of include/t3d.h: scenes above it go through the LBVH (accel 'auto')
 
 SYMBOLS = ("t3d_abi_version", "t3d_device_count", "t3d_create", "t3d_destroy", "t3d_last_error",
            "t3d_upload_scene", "t3d_update_scene", "t3d_render_rows", "t3d_render_rows_device", "t3d_trace_pixel", "t3d_trace_ray",

@@ -251,7 +251,7 @@ class Photon:
         if o.get("bands"):
             return max(1, int(o["bands"]))
         flat = self._flat
-        small_scene = flat is not None and flat.n_tris + flat.n_spheres <= 256
+        small_scene = flat is not None and flat.n_tris + flat.n_spheres <= _native.BRUTE_FORCE_MAX_PRIMS
         samples = int(o["samples"]) if int(o["bounces"]) > 1 else 1
         return 2 if small_scene and int(o["width"]) * int(o["height"]) * samples >= 500_000 and int(o["height"]) >= 16 else 1
 

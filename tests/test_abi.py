@@ -30,6 +30,8 @@ def test_library_exports_every_declared_symbol():
     assert set(names) == set(_native.SYMBOLS)
     lib.t3d_abi_version.restype = C.c_int
     assert lib.t3d_abi_version() == _native.ABI_VERSION
+    # the one constant of the header that Python code mirrors (which scenes Photon renders as two bands, what bench.py prices)
+    assert int(re.search(r"#define\s+T3D_BRUTE_FORCE_MAX_PRIMS\s+(\d+)", open(HEADER).read()).group(1)) == _native.BRUTE_FORCE_MAX_PRIMS
 
 
 def test_ctypes_layout_matches_c(tmp_path):
