@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define T3D_ABI_VERSION 7
+#define T3D_ABI_VERSION 8
 
 enum {
     T3D_OK = 0,
@@ -355,6 +355,18 @@ int t3d_set_rounds(t3d_ctx* ctx, int mode);
 enum { T3D_ACCEL_AUTO = 0, T3D_ACCEL_BRUTE_FORCE = 1, T3D_ACCEL_LBVH = 2 };
 #define T3D_BRUTE_FORCE_MAX_PRIMS 176   /* where the two meet in a closed room; in a sparse scene the LBVH is ahead from 80 on */
 int t3d_set_accel(t3d_ctx* ctx, int mode);
+
+/*
+ * Who builds the hierarchy of scenes uploaded AFTER this call.  Up to `max_prims` triangles + spheres it is cut on the
+ * host, top-down by surface area: the better tree (a mesh in a room reads 6-13 % fewer node records per ray, a uniform
+ * soup 5 %) at about 0.3 us per primitive of host time.  Above it, on the device in Morton order, in a tenth of that
+ * time.  Default T3D_HOST_TREE_MAX_PRIMS, where the host build still costs less than it saves in a 4K frame; raise it
+ * for a large scene that is rendered hundreds of times; 0: always the device.  The environment variable
+ * T3D_HOST_TREE_MAX, when set, takes precedence.  The pictures do not depend on it, t3d_stats.aabb_tests does.
+ * Stands where the reference has Object.buildBVH (T3DE.py:985-1022), always a median split of each mesh.
+ */
+#define T3D_HOST_TREE_MAX_PRIMS 16384
+int t3d_set_host_tree_limit(t3d_ctx* ctx, int max_prims);
 
 /*
  * Cancellation: Photon.render polls cancelCallback() once per pixel and stops the stripe when it answers true

@@ -474,9 +474,6 @@ __device__ __forceinline__ void closest_hit2(GEO_PARAMS, const DevGeo geo, V3 o0
 #define T3D_BVH_LDS_STACK 24   // entries per lane in LDS: 4 waves x 24 x 64 lanes x 4 B = 24 KB per block, 6 blocks per CU
 #endif
 #define T3D_BVH_DEEP_STACK (T3D_BVH_STACK - T3D_BVH_LDS_STACK)
-#ifndef T3D_HOST_TREE_MAX_PRIMS
-#define T3D_HOST_TREE_MAX_PRIMS 16384   // scenes up to this size get the host-built hierarchy (about 5 ms of host time at the limit)
-#endif
 #ifndef T3D_BVH_WAVES
 #define T3D_BVH_WAVES 6   // waves per SIMD the traversal kernels are compiled for
 #endif
@@ -1713,6 +1710,7 @@ struct t3d_ctx {
     void* d_planes = nullptr; void* d_plane_first = nullptr; void* d_tri_uv = nullptr; void* d_tri_n = nullptr;
     void* d_bvh_nodes = nullptr; void* d_bvh_leaves = nullptr; void* d_bvh_spill = nullptr;
     int accel = T3D_ACCEL_AUTO;   // t3d_set_accel
+    int host_tree_max = T3D_HOST_TREE_MAX_PRIMS;   // t3d_set_host_tree_limit
     bool use_bvh = false;         // the uploaded scene is traced through the LBVH
     void* d_tri_meta = nullptr; void* d_spheres = nullptr; void* d_lights = nullptr;
     void* d_shaders = nullptr; void* d_obj_ior = nullptr; void* d_prim_info = nullptr;
@@ -2348,13 +2346,13 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
         if ((rc = upload(c, &d_tri_ab, tri_ab)) || (rc = upload(c, &d_verts, verts))) { hipFree(d_verts); hipFree(d_tri_ab); return rc; }
         float4* nodes = nullptr;
         float4* leaves = nullptr;
-        // Few primitives: the hierarchy is built here, top-down by surface area (t3d_host_tree.h), at about 0.3 us a primitive;
+        // Few primitives: the hierarchy is built here, top-down by surface area (t3d_host_tree.h, t3d_set_host_tree_limit), at about 0.3 us a primitive;
         // many: in Morton order on the device, which takes a tenth of that and gives a tree some 5 % (uniform soup) to 15 %
         // (a mesh in a room) slower to traverse.  T3D_HOST_TREE_MAX moves the line (0: always on the device): worth raising
         // for a scene that is rendered many times.
         HostTree host_tree;
         const char* env_max = getenv("T3D_HOST_TREE_MAX");
-        const long host_max = env_max ? atol(env_max) : T3D_HOST_TREE_MAX_PRIMS;
+        const long host_max = env_max ? atol(env_max) : c->host_tree_max;
         bool host_built = n_prims >= 2 && n_prims <= host_max;
         if (host_built) {
             std::vector<float> blo(3 * (size_t)n_prims), bhi(3 * (size_t)n_prims);
@@ -3079,6 +3077,13 @@ extern "C" int t3d_set_accel(t3d_ctx* c, int mode) {
     if (!c) return T3D_E_INVALID;
     if (mode != T3D_ACCEL_AUTO && mode != T3D_ACCEL_BRUTE_FORCE && mode != T3D_ACCEL_LBVH) { c->err = "t3d_set_accel: unknown mode"; return T3D_E_INVALID; }
     c->accel = mode;
+    return T3D_OK;
+}
+
+extern "C" int t3d_set_host_tree_limit(t3d_ctx* c, int max_prims) {
+    if (!c) return T3D_E_INVALID;
+    if (max_prims < 0) { c->err = "t3d_set_host_tree_limit: negative limit"; return T3D_E_INVALID; }
+    c->host_tree_max = max_prims;
     return T3D_OK;
 }
 

@@ -159,27 +159,40 @@ def test_lbvh_agrees_with_brute_force_on_the_gpu(gpu_ctx, lbvh_ctx):
 
 def test_host_built_and_device_built_trees_give_the_same_picture(lbvh_ctx, monkeypatch):
     """Scenes of up to some thousand primitives get a hierarchy built on the host by surface area, larger ones the
-    Morton-order one built on the device (T3D_HOST_TREE_MAX moves the line).  Either is only a cull: pixels, ids and
+    Morton-order one built on the device (t3d_set_host_tree_limit moves the line).  Either is only a cull: pixels, ids and
     distances must be the same bit for bit; the number of boxes tested is what differs."""
     flat = _soup(3000, 20, 150)
     opt = dict(width=160, height=90, bounces=2, samples=1)
-    monkeypatch.setenv("T3D_HOST_TREE_MAX", "0")
-    lbvh_ctx.upload(flat)
-    dev = lbvh_ctx.render_rows(opt, seed=9, want_radiance=True, want_primary=True)
-    monkeypatch.setenv("T3D_HOST_TREE_MAX", "1000000")
-    lbvh_ctx.upload(flat)
-    host = lbvh_ctx.render_rows(opt, seed=9, want_radiance=True, want_primary=True)
+    from raytracing_amd import _native
+    ctx = _native.Context(0)
+    ctx.set_accel("lbvh")
+    ctx.set_host_tree_limit(0)
+    ctx.upload(flat)
+    dev = ctx.render_rows(opt, seed=9, want_radiance=True, want_primary=True)
+    ctx.set_host_tree_limit(1_000_000)
+    ctx.upload(flat)
+    host = ctx.render_rows(opt, seed=9, want_radiance=True, want_primary=True)
+    monkeypatch.setenv("T3D_HOST_TREE_MAX", "0")          # the environment wins over the call
+    ctx.upload(flat)
+    env = ctx.render_rows(opt, seed=9, want_radiance=True, want_primary=True)
+    # (box counts of one tree vary by a fraction of a percent from run to run: which rays share a wave decides how stale the
+    # best distance is that a postponed leaf is tested against)
+    assert abs(env["stats"]["aabb_tests"] - dev["stats"]["aabb_tests"]) < 0.005 * dev["stats"]["aabb_tests"]
+    monkeypatch.delenv("T3D_HOST_TREE_MAX")
+    with pytest.raises(_native.NativeError, match="negative"):
+        ctx.set_host_tree_limit(-1)
+    ctx.close()
     for key in ("bgr", "radiance", "prim", "prim_t"):
         assert np.array_equal(dev[key], host[key], equal_nan=dev[key].dtype.kind == "f"), key   # prim_t: NaN where nothing is hit
     assert dev["stats"]["queries"] == host["stats"]["queries"] and dev["stats"]["shadow_queries"] == host["stats"]["shadow_queries"]
-    assert host["stats"]["aabb_tests"] != dev["stats"]["aabb_tests"]          # two different trees were traversed
-    assert host["stats"]["aabb_tests"] < 1.02 * dev["stats"]["aabb_tests"]    # and the host's is no worse
+    assert host["stats"]["aabb_tests"] < 0.97 * dev["stats"]["aabb_tests"]    # two different trees were traversed, the host's the better one
     # spheres and the camera moved: the refit keeps whichever tree was built
     from dataclasses import replace
     from raytracing_amd.flatten import OBJ_SPHERE
     centre = flat.obj_center.copy()
     centre[flat.obj_type == OBJ_SPHERE] += np.array([0.05, -0.02, 0.03])
     moved = replace(flat, obj_center=centre, signature_digest=None)
+    lbvh_ctx.upload(flat)
     lbvh_ctx.update(moved)
     refit = lbvh_ctx.render_rows(opt, seed=9, want_primary=True)
     lbvh_ctx.upload(moved)
@@ -212,7 +225,7 @@ def test_too_deep_a_host_tree_is_not_used(lbvh_ctx, monkeypatch):
     lbvh_ctx.upload(flat)
     auto = lbvh_ctx.render_rows(opt, seed=2, want_primary=True)
     assert np.array_equal(dev["bgr"], auto["bgr"]) and np.array_equal(dev["prim"], auto["prim"])
-    assert dev["stats"]["aabb_tests"] == auto["stats"]["aabb_tests"]
+    assert abs(dev["stats"]["aabb_tests"] - auto["stats"]["aabb_tests"]) < 0.005 * dev["stats"]["aabb_tests"]
 
 
 def test_closest_hits_through_lbvh(lbvh_ctx, oracle_mod):
