@@ -209,9 +209,18 @@ class Photon:
     def _camera_scene(self):
         return self.transformedScene if self.options["transformBefore"] else self._scene
 
+    def _new_context(self, device=None):
+        """A context on ``device`` (default: the option of that name) set up as the options ask: ``hostTreeLimit``, absent from
+        the reference, is up to how many primitives a scene's hierarchy is cut on the host by surface area rather than on
+        the device in Morton order (``t3d_set_host_tree_limit``; worth raising for a large scene rendered many times)."""
+        ctx = _native.Context(int(self.options.get("device", 0) if device is None else device))
+        if self.options.get("hostTreeLimit") is not None:
+            ctx.set_host_tree_limit(int(self.options["hostTreeLimit"]))
+        return ctx
+
     def _context(self):
         if self._ctx is None:
-            self._ctx = _native.Context(int(self.options.get("device", 0)))
+            self._ctx = self._new_context()
         return self._ctx
 
     def _prepare(self, force_flatten=False):
@@ -262,7 +271,7 @@ class Photon:
         if want <= 0 or self._flat is None or self._uploaded_digest is None:
             return [self._ctx]
         while len(self._helpers) < want:
-            self._helpers.append([_native.Context(int(self.options.get("device", 0))), None])
+            self._helpers.append([self._new_context(), None])
         for slot in self._helpers[:want]:
             if slot[1] != self._uploaded_digest:
                 slot[0].upload(self._flat)
@@ -454,7 +463,7 @@ class Photon:
         if self._multi_devices != devices:
             for c, _ in self._multi:
                 c.close()
-            self._multi = [[_native.Context(d), None] for d in devices]
+            self._multi = [[self._new_context(d), None] for d in devices]
             self._multi_devices = devices
         flat = flatten_scene(self._scene, self._cache, thorough=True)
         digest = flat.digest()

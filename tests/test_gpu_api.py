@@ -380,6 +380,19 @@ def test_photon_render_in_bands():
     assert np.array_equal(deep2.imageAs("np"), deep.imageAs("np")) and deep2.rays == deep.rays
 
 
+def test_photon_host_tree_limit_option():
+    """options['hostTreeLimit'] (t3d_set_host_tree_limit): who builds the hierarchy of the suzanne scene changes how many
+    boxes a frame tests and nothing else."""
+    import T3DE
+    import T3DR
+    scene = T3DE.Scene.fromJSON(scene_path("config2_suzanne.json"))
+    opts = {"width": 96, "height": 56, "bounces": 3, "samples": 1, "seed": 8}
+    host = T3DR.Photon(scene, dict(opts)).render()                     # 970 primitives: cut on the host by default
+    dev = T3DR.Photon(scene, dict(opts, hostTreeLimit=0)).render()
+    assert np.array_equal(host.imageAs("np"), dev.imageAs("np")) and host.rays == dev.rays
+    assert 0 < host.stats["aabb_tests"] < 0.97 * dev.stats["aabb_tests"]
+
+
 @pytest.mark.parametrize("workload", ["cornell", "monkey"])
 def test_live_scene_updates_in_place_when_only_spheres_lights_or_the_camera_move(workload):
     """Picking on a live scene (transformBefore False, explorer.py:324-355): when only spheres, Lights or the camera moved
