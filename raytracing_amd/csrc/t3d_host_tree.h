@@ -14,8 +14,11 @@
 // a leaf if its range is the single position g) and g + 1 (right, likewise).
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstddef>
+#include <cstdlib>
+#include <thread>
 #include <vector>
 
 struct HostTreeKids { int left, right; };   // same layout as int2
@@ -68,10 +71,11 @@ static inline HostTree host_tree_build(const float* lo, const float* hi, int n) 
         const v4f c = 0.5f * (it.lo + it.hi);
         root.cen.grow(c, c);
     }
-    std::vector<Job> todo{root};
-    while (!todo.empty()) {
-        const Job j = todo.back();
-        todo.pop_back();
+    // one node: choose the cut of job j, partition its items, write the node; the children that are inner nodes go to `out`
+    unsigned n_threads = n >= 32768 ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+    if (const char* env = getenv("T3D_HOST_TREE_THREADS")) n_threads = (unsigned)std::max(1, atoi(env));
+    struct Bins { Box bb[3][BINS]; int cnt[3][BINS]; };
+    auto cut_node = [&](const Job& j, Job* out, int& depth_seen, bool alone) -> int {   // alone: no other node is being cut now
         const int count = j.last - j.first + 1;
         int mid = j.first + count / 2;   // first position of the right part; stays the middle when no cut separates the centres
         Box cl = Box::none(), cr = Box::none();   // boxes of the centres either side
@@ -83,14 +87,29 @@ static inline HostTree host_tree_build(const float* lo, const float* hi, int n) 
         scale[3] = 0.0f;
         int axis = -1, split = 0;
         if (count > 2 && any) {
-            Box bb[3][BINS];
-            int cnt[3][BINS];
-            for (int a = 0; a < 3; ++a) for (int k = 0; k < bins; ++k) { bb[a][k] = Box::none(); cnt[a][k] = 0; }
-            for (int i = j.first; i <= j.last; ++i) {
-                const Item& it = items[i];
-                const v4i k = bins_of(0.5f * (it.lo + it.hi), j.cen.lo, scale, bins);
-                for (int a = 0; a < 3; ++a) { bb[a][k[a]].grow(it.lo, it.hi); cnt[a][k[a]]++; }
+            auto fill = [&](Bins& b, int first, int last) {
+                for (int a = 0; a < 3; ++a) for (int k = 0; k < bins; ++k) { b.bb[a][k] = Box::none(); b.cnt[a][k] = 0; }
+                for (int i = first; i <= last; ++i) {
+                    const Item& it = items[i];
+                    const v4i k = bins_of(0.5f * (it.lo + it.hi), j.cen.lo, scale, bins);
+                    for (int a = 0; a < 3; ++a) { b.bb[a][k[a]].grow(it.lo, it.hi); b.cnt[a][k[a]]++; }
+                }
+            };
+            Bins all;
+            if (alone && n_threads > 1 && count >= 65536) {   // a node at the top of a large tree: its items binned in slices
+                std::vector<Bins> part(n_threads);
+                std::vector<std::thread> pool;
+                for (unsigned w = 0; w < n_threads; ++w)
+                    pool.emplace_back([&, w] { fill(part[w], j.first + (int)((long long)count * w / n_threads), j.first + (int)((long long)count * (w + 1) / n_threads) - 1); });
+                for (std::thread& th : pool) th.join();
+                all = part[0];
+                for (unsigned w = 1; w < n_threads; ++w)
+                    for (int a = 0; a < 3; ++a) for (int k = 0; k < bins; ++k) { all.bb[a][k].join(part[w].bb[a][k]); all.cnt[a][k] += part[w].cnt[a][k]; }
+            } else {
+                fill(all, j.first, j.last);
             }
+            Box (&bb)[3][BINS] = all.bb;
+            int (&cnt)[3][BINS] = all.cnt;
             float best = INFINITY;
             for (int a = 0; a < 3; ++a) {
                 if (!(ext[a] > 0)) continue;
@@ -133,9 +152,44 @@ static inline HostTree host_tree_build(const float* lo, const float* hi, int n) 
         t.kids[j.id] = HostTreeKids{left, right};
         t.parent[left] = j.id;
         t.parent[right] = j.id;
-        t.depth = std::max(t.depth, j.depth + 1);
-        if (g > j.first) todo.push_back(Job{j.first, g, g, j.depth + 1, cl});
-        if (g + 1 < j.last) todo.push_back(Job{g + 1, j.last, g + 1, j.depth + 1, cr});
+        depth_seen = std::max(depth_seen, j.depth + 1);
+        int n_out = 0;
+        if (g > j.first) out[n_out++] = Job{j.first, g, g, j.depth + 1, cl};
+        if (g + 1 < j.last) out[n_out++] = Job{g + 1, j.last, g + 1, j.depth + 1, cr};
+        return n_out;
+    };
+    auto run = [&](std::vector<Job>& todo, int keep_above, std::vector<Job>* small, int& depth_seen, bool alone) {
+        // depth first from `todo`; jobs of at most keep_above positions are set aside in `small` instead (when given)
+        while (!todo.empty()) {
+            const Job j = todo.back();
+            todo.pop_back();
+            Job kids[2];
+            const int nk = cut_node(j, kids, depth_seen, alone);
+            for (int q = 0; q < nk; ++q) {
+                if (small && kids[q].last - kids[q].first + 1 <= keep_above) small->push_back(kids[q]);
+                else todo.push_back(kids[q]);
+            }
+        }
+    };
+    // Large inputs: the top of the tree on this thread until the pieces are small, then the pieces on several threads (they
+    // touch disjoint ranges of the items and disjoint nodes).  The result does not depend on the number of threads.
+    std::vector<Job> todo{root};
+    if (n_threads <= 1) {
+        run(todo, 0, nullptr, t.depth, true);
+    } else {
+        std::vector<Job> small;
+        run(todo, n / (int)(8 * n_threads), &small, t.depth, true);
+        std::sort(small.begin(), small.end(), [](const Job& a, const Job& b) { return a.last - a.first > b.last - b.first; });   // large pieces first
+        std::atomic<size_t> next{0};
+        std::vector<int> depth(n_threads, 0);
+        std::vector<std::thread> pool;
+        for (unsigned w = 0; w < n_threads; ++w)
+            pool.emplace_back([&, w] {
+                std::vector<Job> mine;
+                for (size_t q = next++; q < small.size(); q = next++) { mine.assign(1, small[q]); run(mine, 0, nullptr, depth[w], false); }
+            });
+        for (std::thread& th : pool) th.join();
+        for (int d : depth) t.depth = std::max(t.depth, d);
     }
     for (int i = 0; i < n; ++i) t.order[i] = items[i].prim;
     return t;

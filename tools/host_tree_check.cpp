@@ -1,6 +1,6 @@
 // host_tree_check.cpp -- builds the host-side hierarchy (raytracing_amd/csrc/t3d_host_tree.h) over generated boxes and
 // checks that it is a tree in the device's numbering: every primitive at exactly one leaf position, node ranges nested,
-// child ids at the cut, parents consistent.  Prints "ok <case> n=<n> <milliseconds> cost <cost> depth <depth>" per case; exit status 1 on a violation.
+// child ids at the cut, parents consistent.  Prints "ok <case> n=<n> <milliseconds> cost <cost> depth <depth> tree <hash of order and children>" per case; exit status 1 on a violation.
 //   g++ -O2 -std=c++17 -o host_tree_check tools/host_tree_check.cpp && ./host_tree_check [n ...]
 #include "../raytracing_amd/csrc/t3d_host_tree.h"
 #include <chrono>
@@ -91,7 +91,12 @@ int main(int argc, char** argv) {
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             const bool good = check(t, n, names[kind]);
             ok &= good;
-            printf("%s %-18s n=%d %.3f ms cost %.2f depth %d\n", good ? "ok" : "BAD", names[kind], n, ms, tree_cost(t, lo, hi, n), t.depth);
+            uint64_t h = 1469598103934665603ull;   // FNV-1a over the leaf order and the children of every node
+            auto mix = [&](int v) { h = (h ^ (uint32_t)v) * 1099511628211ull; };
+            for (int v : t.order) mix(v);
+            for (const HostTreeKids& k : t.kids) { mix(k.left); mix(k.right); }
+            printf("%s %-18s n=%d %.3f ms cost %.2f depth %d tree %016llx\n", good ? "ok" : "BAD", names[kind], n, ms, tree_cost(t, lo, hi, n), t.depth,
+                   (unsigned long long)h);
         }
     return ok ? 0 : 1;
 }
