@@ -360,8 +360,7 @@ int t3d_set_accel(t3d_ctx* ctx, int mode);
  * Who builds the hierarchy of scenes uploaded AFTER this call.  Up to `max_prims` triangles + spheres it is cut on the
  * host, top-down by surface area: the better tree (a mesh in a room reads 6-13 % fewer node records per ray, a uniform
  * soup 5 %) at about 0.3 us per primitive of host time (0.15 us from 32768 primitives on: several threads).  Above it, on
- * the device in Morton order, in a tenth of that
- * time.  Default T3D_HOST_TREE_MAX_PRIMS, where the host build still costs less than it saves in a 4K frame; raise it
+ * the device in Morton order, in a tenth of that time.  Default T3D_HOST_TREE_MAX_PRIMS, where the host build still costs less than it saves in a 4K frame; raise it
  * for a large scene that is rendered more than a hundred times; 0: always the device.  The environment variable
  * T3D_HOST_TREE_MAX, when set, takes precedence.  The pictures do not depend on it, t3d_stats.aabb_tests does.
  * Stands where the reference has Object.buildBVH (T3DE.py:985-1022), always a median split of each mesh.
