@@ -48,6 +48,8 @@
 #include <functional>
 #include <map>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <tuple>
@@ -2021,7 +2023,7 @@ static const char* not_finite(const t3d_scene_desc* s, bool triangles) {
          : nullptr;
 }
 
-extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
+static int upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
     if (!c) return T3D_E_INVALID;
     if (!s || s->n_objects < 0 || s->n_tris < 0 || s->n_shaders < 0 || s->n_lights < 0) { c->err = "t3d_upload_scene: bad description"; return T3D_E_INVALID; }
     if (s->n_lights > T3D_MAX_LIGHTS) { c->err = "t3d_upload_scene: too many lights (limit 4096)"; return T3D_E_CAPACITY; }
@@ -2402,6 +2404,20 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
     c->has_scene = true;
     c->scene_gen++;
     return T3D_OK;
+}
+
+// The host side of an upload works in containers (and, for large host-built hierarchies, threads) of the C++ library:
+// what they throw ends here, as an error code like any other.
+extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
+    try {
+        return upload_scene(c, s);
+    } catch (const std::bad_alloc&) {
+        c->err = "t3d_upload_scene: out of host memory"; c->has_scene = false;
+        return T3D_E_CAPACITY;
+    } catch (const std::exception& e) {
+        c->err = std::string("t3d_upload_scene: ") + e.what(); c->has_scene = false;
+        return T3D_E_DEVICE;
+    }
 }
 
 // The uploaded scene again with spheres, Lights or the camera moved (centres, radii, strengths, light positions, the

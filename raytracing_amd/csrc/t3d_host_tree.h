@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdlib>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -98,9 +99,12 @@ static inline HostTree host_tree_build(const float* lo, const float* hi, int n) 
             Bins all;
             if (alone && n_threads > 1 && count >= 65536) {   // a node at the top of a large tree: its items binned in slices
                 std::vector<Bins> part(n_threads);
+                auto slice = [&](unsigned w) { fill(part[w], j.first + (int)((long long)count * w / n_threads), j.first + (int)((long long)count * (w + 1) / n_threads) - 1); };
                 std::vector<std::thread> pool;
-                for (unsigned w = 0; w < n_threads; ++w)
-                    pool.emplace_back([&, w] { fill(part[w], j.first + (int)((long long)count * w / n_threads), j.first + (int)((long long)count * (w + 1) / n_threads) - 1); });
+                unsigned started = 1;   // slice 0 is this thread's; so is every slice whose thread could not be started
+                try { for (; started < n_threads; ++started) pool.emplace_back(slice, started); } catch (const std::system_error&) {}
+                slice(0);
+                for (unsigned w = started; w < n_threads; ++w) slice(w);
                 for (std::thread& th : pool) th.join();
                 all = part[0];
                 for (unsigned w = 1; w < n_threads; ++w)
@@ -182,12 +186,13 @@ static inline HostTree host_tree_build(const float* lo, const float* hi, int n) 
         std::sort(small.begin(), small.end(), [](const Job& a, const Job& b) { return a.last - a.first > b.last - b.first; });   // large pieces first
         std::atomic<size_t> next{0};
         std::vector<int> depth(n_threads, 0);
+        auto worker = [&](unsigned w) {   // pieces are taken from a counter: any number of workers finishes them all
+            std::vector<Job> mine;
+            for (size_t q = next++; q < small.size(); q = next++) { mine.assign(1, small[q]); run(mine, 0, nullptr, depth[w], false); }
+        };
         std::vector<std::thread> pool;
-        for (unsigned w = 0; w < n_threads; ++w)
-            pool.emplace_back([&, w] {
-                std::vector<Job> mine;
-                for (size_t q = next++; q < small.size(); q = next++) { mine.assign(1, small[q]); run(mine, 0, nullptr, depth[w], false); }
-            });
+        try { for (unsigned w = 1; w < n_threads; ++w) pool.emplace_back(worker, w); } catch (const std::system_error&) {}   // fewer threads: slower, same tree
+        worker(0);
         for (std::thread& th : pool) th.join();
         for (int d : depth) t.depth = std::max(t.depth, d);
     }
