@@ -124,6 +124,9 @@ def main():
                          "frame per step (frame g of the run has seed g)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary timings (the other seed mode, one frame per call, the latency of a frame)")
+    ap.add_argument("--background-tree", action="store_true",
+                    help="LBVH scenes above the host-tree limit: a host thread cuts the surface-area tree while the first (untimed) "
+                         "frames are traced through the device's, and the clock starts after it has been adopted (t3d_set_background_tree)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (RCCL over xGMI, one GPU per rank) or gloo: tiles gathered through host memory, and ranks share the "
@@ -193,6 +196,7 @@ def main():
         c = _native.Context(local_rank)
         c.set_accel(args.accel)
         c.set_full_rounds(F >= 3)
+        c.set_background_tree(args.background_tree)
         c.upload(flat)
         ctxs.append(c)
         outs.append(torch.empty((B, tile.nrows, W, 3), dtype=torch.uint8, device=device))
@@ -309,6 +313,8 @@ def main():
     grow = Run(False)
     for _ in range(F):
         grow.step(B, want_stats=True)
+    # where the hierarchy of an LBVH scene comes from; a tree still being cut on a host thread is waited for and adopted here
+    hierarchy = sorted({c.tree_status(wait=True) for c in ctxs})
     for c in ctxs:
         c.set_timing(False)
     vary = not args.fixed_seed
@@ -432,6 +438,9 @@ def main():
                        "samples": options["samples"], "triangles": T, "spheres_and_lights": S,
                        "lights": int(len(flat.light_strength)), "partition": f"{args.partition} rows x{world}",
                        "frames_in_flight": F * B, "calls_in_flight": F, "frames_per_call": B,
+                       # none: brute force; device: Morton order; host: surface area, cut during the upload; background: the
+                       # same, cut on a host thread during the first untimed frames (--background-tree)
+                       "hierarchy": "/".join(hierarchy),
                        # averages over the timed frames (exact: every timed call was rendered again with statistics)
                        "queries_per_frame": round(traced / steps, 1),
                        "shadow_rays_answered_untraced_per_frame": round(totals["shadow_culled"] / steps, 1),

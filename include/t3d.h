@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define T3D_ABI_VERSION 8
+#define T3D_ABI_VERSION 9
 
 enum {
     T3D_OK = 0,
@@ -367,6 +367,32 @@ int t3d_set_accel(t3d_ctx* ctx, int mode);
  */
 #define T3D_HOST_TREE_MAX_PRIMS 16384
 int t3d_set_host_tree_limit(t3d_ctx* ctx, int max_prims);
+
+/*
+ * The better tree without the wait.  With `on` non-zero, a scene uploaded AFTER this call whose hierarchy is built on the
+ * device (more primitives than the limit above) is traced through that Morton-order tree at once, while a host thread
+ * of the library cuts the surface-area tree of the same primitives (0.15 us per primitive on up to eight threads); the
+ * first render, trace or closest-hit call that finds it finished waits for the context's streams, writes the new order
+ * and links over the old ones, refits and packs (a few milliseconds, once) and goes on through the better tree --
+ * buffers and addresses stay what they were, so do the pictures (either tree is only a cull); t3d_stats.aabb_tests
+ * drops.  For a caller that renders an unchanged or merely moving scene (t3d_update_scene) many times.  Off by default:
+ * a caller that renders one frame per upload gains nothing.  A too deep surface-area tree is dropped, as at upload.
+ * t3d_upload_scene and t3d_destroy wait for a build that is still running.  t3d_render_rows_device_static never adopts
+ * (the swap copies from pageable host memory): it goes on through the tree that is in place.
+ *
+ * t3d_tree_status says where the uploaded scene's hierarchy comes from; with `wait` non-zero it first waits for a
+ * running build and adopts its tree (what a benchmark calls before it starts its clock).
+ * Stands where the reference has Object.buildBVH (T3DE.py:985-1022), which always runs before the first pixel.
+ */
+enum {
+    T3D_TREE_NONE = 0,        /* no scene, or one that is traced without a hierarchy */
+    T3D_TREE_DEVICE = 1,      /* Morton order, built on the device */
+    T3D_TREE_HOST = 2,        /* surface area, built on the host during t3d_upload_scene */
+    T3D_TREE_BUILDING = 3,    /* the device's, while the host's is being built in the background */
+    T3D_TREE_BACKGROUND = 4   /* the host's, adopted after the upload */
+};
+int t3d_set_background_tree(t3d_ctx* ctx, int on);
+int t3d_tree_status(t3d_ctx* ctx, int wait);   /* T3D_TREE_* or a negative T3D_E_* */
 
 /*
  * Cancellation: Photon.render polls cancelCallback() once per pixel and stops the stripe when it answers true

@@ -12,12 +12,12 @@ import numpy as np
 from .flatten import FlatScene, Opts, SceneDesc, Stats, make_opts
 
 LIB_PATH = os.environ.get("T3D_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libt3d_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 BRUTE_FORCE_MAX_PRIMS = 176   # T3D_BRUTE_FORCE_MAX_PRIMS of include/t3d.h: scenes above it go through the LBVH (accel 'auto')
 
 SYMBOLS = ("t3d_abi_version", "t3d_device_count", "t3d_create", "t3d_destroy", "t3d_last_error",
            "t3d_upload_scene", "t3d_update_scene", "t3d_render_rows", "t3d_render_rows_device", "t3d_trace_pixel", "t3d_trace_ray",
-           "t3d_closest_hits", "t3d_last_call_stats", "t3d_set_timing", "t3d_set_accel", "t3d_set_host_tree_limit", "t3d_set_rounds", "t3d_set_cancel",
+           "t3d_closest_hits", "t3d_last_call_stats", "t3d_set_timing", "t3d_set_accel", "t3d_set_host_tree_limit", "t3d_set_background_tree", "t3d_tree_status", "t3d_set_rounds", "t3d_set_cancel",
            "t3d_render_rows_async", "t3d_host_alloc", "t3d_host_free", "t3d_render_frame_multi",
            "t3d_render_rows_device_static", "t3d_graph_counters", "t3d_render_rows_device_split", "t3d_render_rows_async_split",
            "t3d_post_upscale_device", "t3d_post_denoise_device", "t3d_post_upscale", "t3d_post_denoise")
@@ -119,6 +119,10 @@ def load():
     lib.t3d_set_accel.argtypes = [C.c_void_p, C.c_int]
     lib.t3d_set_host_tree_limit.restype = C.c_int
     lib.t3d_set_host_tree_limit.argtypes = [C.c_void_p, C.c_int]
+    lib.t3d_set_background_tree.restype = C.c_int
+    lib.t3d_set_background_tree.argtypes = [C.c_void_p, C.c_int]
+    lib.t3d_tree_status.restype = C.c_int
+    lib.t3d_tree_status.argtypes = [C.c_void_p, C.c_int]
     lib.t3d_render_rows_async.restype = C.c_int
     lib.t3d_render_rows_async.argtypes = [C.c_void_p, P(Opts), C.c_int, C.c_int, C.c_void_p]
     lib.t3d_render_frame_multi.restype = C.c_int
@@ -308,6 +312,20 @@ class Context:
         """Scenes of up to this many primitives, uploaded after this call, get the hierarchy that is cut on the host by
         surface area (better, slower to build); larger ones the device's Morton-order one.  0: always the device."""
         self._check(self._lib.t3d_set_host_tree_limit(self._h, int(max_prims)), "t3d_set_host_tree_limit")
+
+    def set_background_tree(self, on: bool):
+        """Scenes uploaded after this call whose hierarchy the device builds are traced through it at once while a host
+        thread cuts the surface-area tree, which the first call that finds it finished puts in its place."""
+        self._check(self._lib.t3d_set_background_tree(self._h, 1 if on else 0), "t3d_set_background_tree")
+
+    TREE_STATUS = {0: "none", 1: "device", 2: "host", 3: "building", 4: "background"}
+
+    def tree_status(self, wait: bool = False) -> str:
+        """Where the uploaded scene's hierarchy comes from: 'none' | 'device' | 'host' | 'building' | 'background'.
+        ``wait``: first wait for a background build and adopt its tree."""
+        rc = self._lib.t3d_tree_status(self._h, 1 if wait else 0)
+        self._check(min(rc, 0), "t3d_tree_status")
+        return self.TREE_STATUS[rc]
 
     def set_full_rounds(self, full: bool):
         """Always 128 rays per trace round (for callers that keep several bands in flight) instead of the adaptive cut."""

@@ -46,7 +46,9 @@
 #include <algorithm>
 #include <cmath>
 #include <functional>
+#include <atomic>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <stdexcept>
@@ -1699,6 +1701,17 @@ struct Work {
     uint64_t gen = 0;    // counts (re)allocations: a launch graph holds the addresses
 };
 
+// A surface-area hierarchy being cut on a host thread while the scene is already traced through the device's tree
+// (t3d_set_background_tree).  The thread touches nothing but this object; the context looks at `state` (acquire) and
+// joins the thread before it reads the tree or lets the object go.
+struct BackgroundTree {
+    std::thread th;
+    std::atomic<int> state{0};       // 0: building, 1: the tree is there, 2: the build failed (out of memory)
+    std::vector<float> lo, hi;       // [3n] boxes of the primitives as uploaded
+    int n = 0;
+    HostTree tree;
+};
+
 struct t3d_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -1714,6 +1727,9 @@ struct t3d_ctx {
     int accel = T3D_ACCEL_AUTO;   // t3d_set_accel
     int host_tree_max = T3D_HOST_TREE_MAX_PRIMS;   // t3d_set_host_tree_limit
     bool use_bvh = false;         // the uploaded scene is traced through the LBVH
+    bool background_tree = false; // t3d_set_background_tree
+    int tree_source = T3D_TREE_NONE;            // T3D_TREE_*: where the uploaded scene's hierarchy comes from
+    std::unique_ptr<BackgroundTree> bg_tree;    // a build that has not been adopted or dropped yet
     void* d_tri_meta = nullptr; void* d_spheres = nullptr; void* d_lights = nullptr;
     void* d_shaders = nullptr; void* d_obj_ior = nullptr; void* d_prim_info = nullptr;
     int n_objects = 0, n_sphere_objs = 0, n_light_objs = 0;
@@ -1881,7 +1897,15 @@ extern "C" int t3d_create(int device, t3d_ctx** out) {
     return T3D_OK;
 }
 
+static void drop_background_tree(t3d_ctx* c) {
+    if (!c->bg_tree) return;
+    if (c->bg_tree->th.joinable()) c->bg_tree->th.join();   // (a build cannot be interrupted: at most a few tenths of a second)
+    c->bg_tree.reset();
+}
+
 static void free_scene(t3d_ctx* c) {
+    drop_background_tree(c);
+    c->tree_source = T3D_TREE_NONE;
     c->lbvh_work.release();
     hipFree(c->d_lbvh_verts); hipFree(c->d_lbvh_tri_ab);
     c->d_lbvh_verts = c->d_lbvh_tri_ab = nullptr;
@@ -2356,8 +2380,8 @@ static int upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
         const char* env_max = getenv("T3D_HOST_TREE_MAX");
         const long host_max = env_max ? atol(env_max) : c->host_tree_max;
         bool host_built = n_prims >= 2 && n_prims <= host_max;
-        if (host_built) {
-            std::vector<float> blo(3 * (size_t)n_prims), bhi(3 * (size_t)n_prims);
+        auto prim_boxes = [&](std::vector<float>& blo, std::vector<float>& bhi) {   // boxes of the primitives in device order
+            blo.resize(3 * (size_t)n_prims); bhi.resize(3 * (size_t)n_prims);
             for (int k = 0; k < s->n_tris; ++k)
                 for (int a = 0; a < 3; ++a) {
                     const float* v = &verts[9 * (size_t)k];
@@ -2369,6 +2393,10 @@ static int upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
                 const float r = sqrtf(sp.r2), ce[3] = {sp.cx, sp.cy, sp.cz};
                 for (int a = 0; a < 3; ++a) { blo[3 * (s->n_tris + q) + a] = ce[a] - r; bhi[3 * (s->n_tris + q) + a] = ce[a] + r; }
             }
+        };
+        if (host_built) {
+            std::vector<float> blo, bhi;
+            prim_boxes(blo, bhi);
             host_tree = host_tree_build(blo.data(), bhi.data(), n_prims);
             // a surface-area tree has no bound on its depth (sizes in geometric progression give a chain); the traversal
             // stack is sized for the Morton tree's (30 key bits + ties): deeper than that, take the Morton tree
@@ -2383,6 +2411,23 @@ static int upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
         // benchmark workloads, whose stacks stay within the LDS part)
         HIPCHK(c, hipMalloc(&c->d_bvh_spill, sizeof(int) * 64 * T3D_BVH_DEEP_STACK * (size_t)c->n_sm * T3D_BVH_WAVES * T3D_WAVES));
         c->use_bvh = true;
+        c->tree_source = host_built ? T3D_TREE_HOST : T3D_TREE_DEVICE;
+        if (!host_built && c->background_tree && n_prims >= 2) {
+            // the surface-area tree of the same primitives, cut on a thread of its own while the caller renders through the
+            // device's tree; adopt_background_tree puts it in place.  No thread to be had: the device's tree stays.
+            std::unique_ptr<BackgroundTree> bg(new BackgroundTree());
+            bg->n = n_prims;
+            prim_boxes(bg->lo, bg->hi);
+            BackgroundTree* b = bg.get();
+            try {
+                bg->th = std::thread([b] {
+                    try { b->tree = host_tree_build(b->lo.data(), b->hi.data(), b->n); b->state.store(1, std::memory_order_release); }
+                    catch (...) { b->state.store(2, std::memory_order_release); }
+                });
+                c->bg_tree = std::move(bg);
+                c->tree_source = T3D_TREE_BUILDING;
+            } catch (const std::system_error&) {}
+        }
     }
     DevScene& d = c->sc;
     d.bvh.nodes = (const float4*)c->d_bvh_nodes; d.bvh.leaves = (const float4*)c->d_bvh_leaves; d.bvh.n_prims = n_prims;
@@ -2418,6 +2463,55 @@ extern "C" int t3d_upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
         c->err = std::string("t3d_upload_scene: ") + e.what(); c->has_scene = false;
         return T3D_E_DEVICE;
     }
+}
+
+// Puts the hierarchy that a host thread has cut since the upload (BackgroundTree) in place of the device's: the order of
+// the leaves, the links and the parents are written over the build's working arrays, then the boxes are refitted and the
+// records packed into the buffers the kernels already read -- no address changes, launch graphs stay valid.  Called at
+// the start of every entry point that traces; does nothing (one atomic read) while the build runs, unless `wait`.
+static int adopt_background_tree(t3d_ctx* c, bool wait = false) {
+    if (!c->bg_tree) return T3D_OK;
+    BackgroundTree& b = *c->bg_tree;
+    if (!wait && b.state.load(std::memory_order_acquire) == 0) return T3D_OK;
+    if (b.th.joinable()) b.th.join();
+    std::unique_ptr<BackgroundTree> done = std::move(c->bg_tree);   // gone whatever happens below
+    c->tree_source = T3D_TREE_DEVICE;
+    const int n = c->up_tris + (int)c->h_spheres.size();
+    if (done->state.load(std::memory_order_acquire) != 1 || !c->use_bvh || !c->has_scene || done->n != n ||
+        done->tree.depth > T3D_BVH_STACK / 2)   // (deeper than the traversal stack provides for: see upload_scene)
+        return T3D_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    // nothing that reads the records may be in flight: the context's streams and the stream of the most recent call
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->shadow_stream));
+    // (a caller's stream that has been destroyed since is an error of no consequence here)
+    if (c->last_stream && c->last_stream != c->stream && hipStreamSynchronize(c->last_stream) != hipSuccess) (void)hipGetLastError();
+    LbvhWork& w = c->lbvh_work;
+    const HostTree& t = done->tree;
+    HIPCHK(c, hipMemcpyAsync(w.vals[w.sorted], t.order.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(w.kids, t.kids.data(), sizeof(HostTreeKids) * (size_t)(n - 1), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(w.parent, t.parent.data(), sizeof(int) * (2 * (size_t)n - 1), hipMemcpyHostToDevice, c->stream));
+    hipError_t e = lbvh_refit(c->stream, w, (const float*)c->d_lbvh_verts, (const float4*)c->d_lbvh_tri_ab, c->up_tris,
+                              (const DevSphere*)c->d_spheres, (int)c->h_spheres.size(), (float4*)c->d_bvh_nodes, (float4*)c->d_bvh_leaves);
+    if (e != hipSuccess) { c->err = std::string("background tree: refit failed: ") + hipGetErrorString(e); c->has_scene = false; return T3D_E_DEVICE; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // the tree's vectors go with `done`; callers' streams start after this
+    c->tree_source = T3D_TREE_BACKGROUND;
+    return T3D_OK;
+}
+
+extern "C" int t3d_set_background_tree(t3d_ctx* c, int on) {
+    if (!c) return T3D_E_INVALID;
+    c->background_tree = on != 0;
+    return T3D_OK;
+}
+
+extern "C" int t3d_tree_status(t3d_ctx* c, int wait) {
+    if (!c) return T3D_E_INVALID;
+    if (wait || (c->bg_tree && c->bg_tree->state.load(std::memory_order_acquire) != 0)) {
+        const int rc = adopt_background_tree(c, true);
+        if (rc != T3D_OK) return rc;
+    }
+    return c->has_scene && c->use_bvh ? c->tree_source : T3D_TREE_NONE;
 }
 
 // The uploaded scene again with spheres, Lights or the camera moved (centres, radii, strengths, light positions, the
@@ -2922,6 +3016,7 @@ extern "C" int t3d_render_rows_device(t3d_ctx* c, const t3d_opts* o, int row0, i
     if (!bgr_device) { c->err = "bgr output is required"; return T3D_E_INVALID; }
     HIPCHK(c, hipSetDevice(c->device));
     if ((rc = take_sticky(c)) != T3D_OK) return rc;
+    if ((rc = adopt_background_tree(c)) != T3D_OK) return rc;
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     if (stats) memset(stats, 0, sizeof *stats);
     const int S = o->bounces > 1 ? o->samples : 1;
@@ -3436,6 +3531,7 @@ static int trace_single(t3d_ctx* c, const t3d_opts* o, const RenderParams& singl
     HIPCHK(c, hipSetDevice(c->device));
     int rc = take_sticky(c);
     if (rc != T3D_OK) return rc;
+    if ((rc = adopt_background_tree(c)) != T3D_OK) return rc;
     const int worst = (1 << (o->bounces + 1)) - 1;   // a full binary tree: T3D_MAX_BOUNCES keeps this below 2^15
     const int dbg_cap = worst;
     if (dbg_cap > c->dbg_alloc) {
@@ -3508,6 +3604,7 @@ extern "C" int t3d_closest_hits(t3d_ctx* c, int n, const float* origins, const f
     if (n < 0 || !origins || !dirs || !out_obj || !out_face || !out_t || !out_dirflag) { c->err = "t3d_closest_hits: bad argument"; return T3D_E_INVALID; }
     if (n == 0) return T3D_OK;
     HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = adopt_background_tree(c)) return rc;
     // The rays and the answers live in one pinned host buffer of the context that the kernel reads and writes in place
     // (44 bytes in, 32 bytes out per ray over the host link): a picked pixel is a launch and a wait, with no device
     // allocation and no staged copies.

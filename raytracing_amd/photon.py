@@ -216,6 +216,11 @@ class Photon:
         ctx = _native.Context(int(self.options.get("device", 0) if device is None else device))
         if self.options.get("hostTreeLimit") is not None:
             ctx.set_host_tree_limit(int(self.options["hostTreeLimit"]))
+        if self.options.get("backgroundTree"):
+            # also absent from the reference: a scene above that limit is traced through the device's tree at once while a
+            # host thread cuts the better one, adopted by the first call that finds it finished (t3d_set_background_tree;
+            # for a scene that is rendered again and again, e.g. with a moving camera)
+            ctx.set_background_tree(True)
         return ctx
 
     def _context(self):

@@ -393,6 +393,24 @@ def test_photon_host_tree_limit_option():
     assert 0 < host.stats["aabb_tests"] < 0.97 * dev.stats["aabb_tests"]
 
 
+def test_photon_background_tree_option():
+    """options['backgroundTree'] (t3d_set_background_tree): with the device building the hierarchy of the suzanne scene, a
+    host thread cuts the surface-area tree meanwhile; once it is in place the frames test as few boxes as with the tree cut
+    at upload, and every frame on the way is the same picture."""
+    import T3DE
+    import T3DR
+    scene = T3DE.Scene.fromJSON(scene_path("config2_suzanne.json"))
+    opts = {"width": 96, "height": 56, "bounces": 3, "samples": 1, "seed": 8}
+    host = T3DR.Photon(scene, dict(opts)).render()
+    ph = T3DR.Photon(scene, dict(opts, hostTreeLimit=0, backgroundTree=True))
+    frames = [ph.render() for _ in range(3)]
+    assert ph._ctx.tree_status(wait=True) == "background" and ph.uploads == 1
+    frames.append(ph.render())
+    for f in frames:
+        assert np.array_equal(host.imageAs("np"), f.imageAs("np")) and host.rays == f.rays
+    assert abs(frames[-1].stats["aabb_tests"] - host.stats["aabb_tests"]) < 0.005 * host.stats["aabb_tests"]
+
+
 @pytest.mark.parametrize("workload", ["cornell", "monkey"])
 def test_live_scene_updates_in_place_when_only_spheres_lights_or_the_camera_move(workload):
     """Picking on a live scene (transformBefore False, explorer.py:324-355): when only spheres, Lights or the camera moved

@@ -200,6 +200,88 @@ def test_host_built_and_device_built_trees_give_the_same_picture(lbvh_ctx, monke
     assert np.array_equal(refit["bgr"], rebuilt["bgr"]) and np.array_equal(refit["prim"], rebuilt["prim"])
 
 
+def test_background_tree_is_adopted_between_two_calls():
+    """t3d_set_background_tree: a scene whose hierarchy the device builds is traced through that tree at once while a host
+    thread cuts the surface-area tree; the first call that finds it finished puts it in place.  Same buffers, same
+    pictures bit for bit, fewer boxes tested -- through plain calls, a launch graph replayed across the swap, a moved
+    sphere (refit of the adopted tree) and picking; uploads and the context's end wait for a build that still runs."""
+    import torch
+    from dataclasses import replace
+    from raytracing_amd import _native
+    from raytracing_amd.flatten import OBJ_SPHERE
+    flat = _soup(15000, 50, 500)
+    opt = dict(width=160, height=90, bounces=2, samples=1)
+    ctx = _native.Context(0)
+    try:
+        ctx.set_host_tree_limit(0)               # the device builds
+        ctx.upload(flat)
+        assert ctx.tree_status() == "device"
+        dev = ctx.render_rows(opt, seed=9, want_radiance=True, want_primary=True)
+        ctx.set_host_tree_limit(1_000_000)       # the host builds, at upload
+        ctx.upload(flat)
+        assert ctx.tree_status() == "host"
+        host = ctx.render_rows(opt, seed=9, want_radiance=True, want_primary=True)
+        ctx.set_host_tree_limit(0)
+        ctx.set_background_tree(True)
+        ctx.upload(flat)
+        assert ctx.tree_status() in ("building", "background")     # (a call that finds the build finished adopts it)
+        # a band asked for again and again becomes a launch graph, which must survive the swap: same addresses
+        out = torch.empty((opt["height"], opt["width"], 3), dtype=torch.uint8, device="cuda:0")
+        stream = torch.cuda.Stream("cuda:0")
+        for _ in range(4):
+            ctx.render_rows_device(opt, 9, 0, opt["height"], out.data_ptr(), stream=stream.cuda_stream)
+        assert ctx.tree_status(wait=True) == "background"
+        for _ in range(2):
+            ctx.render_rows_device(opt, 9, 0, opt["height"], out.data_ptr(), stream=stream.cuda_stream)
+        stream.synchronize()
+        ctx.last_call_stats()
+        assert np.array_equal(out.cpu().numpy(), dev["bgr"])
+        bg = ctx.render_rows(opt, seed=9, want_radiance=True, want_primary=True)
+        for key in ("bgr", "radiance", "prim", "prim_t"):
+            assert np.array_equal(dev[key], bg[key], equal_nan=dev[key].dtype.kind == "f"), key
+            assert np.array_equal(host[key], bg[key], equal_nan=dev[key].dtype.kind == "f"), key
+        assert bg["stats"]["queries"] == dev["stats"]["queries"]
+        assert bg["stats"]["aabb_tests"] < 0.97 * dev["stats"]["aabb_tests"]
+        assert abs(bg["stats"]["aabb_tests"] - host["stats"]["aabb_tests"]) < 0.005 * host["stats"]["aabb_tests"]   # the same tree
+        # spheres moved: the adopted tree is refitted like any other
+        centre = flat.obj_center.copy()
+        centre[flat.obj_type == OBJ_SPHERE] += np.array([0.05, -0.02, 0.03])
+        moved = replace(flat, obj_center=centre, signature_digest=None)
+        ctx.update(moved)
+        assert ctx.tree_status() == "background"
+        refit = ctx.render_rows(opt, seed=9, want_primary=True)
+        # an upload while a build runs waits for it and starts the next; so does the context's end; a moved scene before the
+        # adoption is adopted with its spheres where they are now; picking adopts as well
+        ctx.upload(flat)
+        ctx.upload(moved)
+        assert ctx.tree_status() in ("building", "background")
+        ctx.update(flat)
+        ctx.update(moved)
+        rng = np.random.default_rng(5)
+        origins = np.tile(np.array([0.3713, 0.2117, -28.8]), (64, 1))
+        dirs = rng.normal(size=(64, 3)) * 0.2 + np.array([0.0, 0.0, 1.0])
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        early = ctx.closest_hits(origins, dirs, lights=True, back_cull=True)
+        assert ctx.tree_status(wait=True) == "background"
+        late = ctx.closest_hits(origins, dirs, lights=True, back_cull=True)
+        for key in early:
+            assert np.array_equal(early[key], late[key], equal_nan=True), key
+        rebuilt = ctx.render_rows(opt, seed=9, want_primary=True)
+        assert np.array_equal(refit["bgr"], rebuilt["bgr"]) and np.array_equal(refit["prim"], rebuilt["prim"])
+        # a scene the host builds at upload, or one without a hierarchy, starts no thread
+        ctx.set_host_tree_limit(1_000_000)
+        ctx.upload(flat)
+        assert ctx.tree_status() == "host"
+        ctx.set_host_tree_limit(0)
+        ctx.set_accel("brute")
+        ctx.upload(_soup(20, 2, 3))
+        assert ctx.tree_status(wait=True) == "none"
+        ctx.set_accel("auto")
+        ctx.upload(flat)                          # ... and the context ends while this build runs
+    finally:
+        ctx.close()
+
+
 def test_too_deep_a_host_tree_is_not_used(lbvh_ctx, monkeypatch):
     """Triangles whose sizes fall off geometrically over 27 decades, 8 coincident copies of each: the surface-area build
     peels the large ones off a few per level and ends 52 levels deep, more than the traversal stack is sized for; the
