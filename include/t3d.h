@@ -376,7 +376,8 @@ int t3d_set_host_tree_limit(t3d_ctx* ctx, int max_prims);
  * and links over the old ones, refits and packs (a few milliseconds, once) and goes on through the better tree --
  * buffers and addresses stay what they were, so do the pictures (either tree is only a cull); t3d_stats.aabb_tests
  * drops.  For a caller that renders an unchanged or merely moving scene (t3d_update_scene) many times.  Off by default:
- * a caller that renders one frame per upload gains nothing.  A too deep surface-area tree is dropped, as at upload.
+ * a caller that renders one frame per upload gains nothing (the environment variable T3D_BACKGROUND_TREE, read by
+ * t3d_create, gives the initial value).  A too deep surface-area tree is dropped, as at upload.
  * t3d_upload_scene and t3d_destroy wait for a build that is still running.  t3d_render_rows_device_static never adopts
  * (the swap copies from pageable host memory): it goes on through the tree that is in place.
  *

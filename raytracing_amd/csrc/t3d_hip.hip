@@ -1863,6 +1863,7 @@ extern "C" int t3d_create(int device, t3d_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_sm = prop.multiProcessorCount;
     if (getenv("T3D_NO_GRAPHS")) c->graphs_enabled = false;
+    if (const char* bg = getenv("T3D_BACKGROUND_TREE")) c->background_tree = atoi(bg) != 0;   // t3d_set_background_tree's initial value
     // working-set budget of one band in MiB (default 48 GiB): small values make small frames take the paths of huge ones
     if (const char* mb = getenv("T3D_MEM_BUDGET_MB")) { const long v = atol(mb); if (v > 0) c->mem_budget = (size_t)v << 20; }
     if (hipMalloc((void**)&c->d_cnt_pair[0], sizeof(Counters)) != hipSuccess || hipMalloc((void**)&c->d_cnt_pair[1], sizeof(Counters)) != hipSuccess ||
