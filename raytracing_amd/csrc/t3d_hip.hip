@@ -47,6 +47,7 @@
 #include <cmath>
 #include <functional>
 #include <atomic>
+#include <chrono>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -1960,8 +1961,25 @@ extern "C" void t3d_destroy(t3d_ctx* c) {
     delete c;
 }
 
+// Host staging of the large per-triangle records: not filled on allocation (a std::vector would be, on one thread, touching
+// every page first), so that the threads which write the records are the ones that touch their pages.  Every entry
+// must be written by the code that fills it.
 template <typename T>
-static int upload(t3d_ctx* c, void** dst, const std::vector<T>& v) {
+struct HostArray {
+    T* p; size_t n;
+    explicit HostArray(size_t count) : p((T*)malloc(sizeof(T) * (count ? count : 1))), n(count) { if (!p) throw std::bad_alloc(); }
+    ~HostArray() { free(p); }
+    HostArray(const HostArray&) = delete;
+    HostArray& operator=(const HostArray&) = delete;
+    T& operator[](size_t i) { return p[i]; }
+    const T* data() const { return p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+};
+
+template <typename V>
+static int upload(t3d_ctx* c, void** dst, const V& v) {
+    typedef typename std::remove_cv<typename std::remove_reference<decltype(*v.data())>::type>::type T;
     size_t bytes = sizeof(T) * (v.empty() ? 1 : v.size());
     HIPCHK(c, hipMalloc(dst, bytes));
     if (!v.empty()) {
@@ -1978,6 +1996,22 @@ static int upload(t3d_ctx* c, void** dst, const std::vector<T>& v) {
 // process's few hardware queues, and a caller that renders on streams of its own -- four chains on four streams --
 // then shares those queues with the contexts' idle streams (one rank's share of an 8-GPU frame, four calls in flight:
 // 0.113 ms per frame against 0.068).
+// The per-triangle loops of an upload on several host threads: f(first, last) over slices of [0, n).  Small inputs, and
+// slices whose thread cannot be started, run on the calling thread; f must not throw.
+template <typename F>
+static void parallel_slices(size_t n, F f) {
+    unsigned n_threads = n >= 65536 ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+    if (const char* env = getenv("T3D_UPLOAD_THREADS")) n_threads = n >= 2 ? (unsigned)std::max(1, atoi(env)) : 1u;
+    if (n_threads <= 1) { f((size_t)0, n); return; }
+    auto slice = [&](unsigned w) { f(n * w / n_threads, n * (w + 1) / n_threads); };
+    std::vector<std::thread> pool;
+    unsigned started = 1;
+    try { for (; started < n_threads; ++started) pool.emplace_back(slice, started); } catch (const std::system_error&) {}
+    slice(0);
+    for (unsigned w = started; w < n_threads; ++w) slice(w);
+    for (std::thread& th : pool) th.join();
+}
+
 struct UploadStream {
     t3d_ctx* c;
     explicit UploadStream(t3d_ctx* ctx) : c(ctx) {
@@ -2062,16 +2096,27 @@ static int upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
         if (missing) { c->err = std::string("t3d_upload_scene: ") + missing + " is null"; return T3D_E_INVALID; }
     }
     // geometry that is not a finite number has no place in a hierarchy or a plane group: refuse it by name
+    // T3D_UPLOAD_TRACE: where an upload's time goes, phase by phase, on stderr
+    const bool trace_phases = getenv("T3D_UPLOAD_TRACE") != nullptr;
+    auto t_phase = std::chrono::steady_clock::now();
+    auto phase = [&](const char* name) {
+        if (!trace_phases) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "t3d_upload_scene: %-28s %8.2f ms\n", name, std::chrono::duration<double, std::milli>(now - t_phase).count());
+        t_phase = now;
+    };
     if (const char* bad = not_finite(s, true)) { c->err = std::string("t3d_upload_scene: ") + bad + " is not finite"; return T3D_E_INVALID; }
+    phase("arguments checked");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_scene(c);
     UploadStream upload_stream(c);
+    phase("previous scene released");
 
     // Triangles are grouped by supporting plane (same unit normal to 1e-7 and same offset to 1e-6, float64):
     // groups in order of their first triangle, triangles inside a group in their original order.
     struct Tri { int obj, face, shader; double n[3], nv0; };
-    std::vector<Tri> tris((size_t)s->n_tris);
+    HostArray<Tri> tris((size_t)s->n_tris);   // every triangle belongs to exactly one object (checked below), which writes its entry
     std::vector<std::vector<int>> groups;
     std::map<std::tuple<long long, long long, long long, long long>, int> plane_index;
     std::vector<DevSphere> spheres;
@@ -2091,6 +2136,28 @@ static int upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
         if (ty == T3D_OBJ_MESH) {
             int b0 = s->obj_tri_begin[o], n = s->obj_tri_count[o];
             if (b0 < 0 || n < 0 || b0 + n > s->n_tris) { c->err = "t3d_upload_scene: triangle range out of bounds"; return T3D_E_INVALID; }
+            if (want_bvh) {
+                // (the triangles of one object are distinct entries: slices of them can be filled side by side)
+                std::atomic<int> bad{0};
+                parallel_slices((size_t)n, [&](size_t first, size_t last) {
+                    for (size_t k = first; k < last; ++k) {
+                        const int t = b0 + (int)k;
+                        const double* v = s->tri_verts + 9 * (size_t)t;
+                        const double e1[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]}, e2[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]};
+                        const double nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
+                        Tri& T = tris[t];
+                        T.n[0] = nx; T.n[1] = ny; T.n[2] = nz; T.nv0 = nx * v[0] + ny * v[1] + nz * v[2];
+                        T.obj = o; T.face = (int)k; T.shader = s->tri_shader[t];
+                        if (T.shader < 0 || T.shader >= s->n_shaders) bad.store(1, std::memory_order_relaxed);
+                        if (seen[t]) bad.store(2, std::memory_order_relaxed);
+                        seen[t] = 1;
+                    }
+                });
+                if (bad.load() == 1) { c->err = "t3d_upload_scene: triangle shader index out of range"; return T3D_E_INVALID; }
+                if (bad.load() == 2) { c->err = "t3d_upload_scene: triangle ranges of two objects overlap"; return T3D_E_INVALID; }
+                n_owned += n;
+                continue;
+            }
             for (int k = 0; k < n; ++k) {
                 int t = b0 + k;
                 const double* v = s->tri_verts + 9 * (size_t)t;
@@ -2104,7 +2171,6 @@ static int upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
                 if (seen[t]) { c->err = "t3d_upload_scene: triangle ranges of two objects overlap"; return T3D_E_INVALID; }
                 seen[t] = 1;
                 ++n_owned;
-                if (want_bvh) continue;
                 int g = -1;
                 if (nn > 0) {
                     double len = sqrt(nn), off = T.nv0 / len;
@@ -2128,6 +2194,7 @@ static int upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
         }
     }
     if (n_owned != s->n_tris) { c->err = "t3d_upload_scene: triangles not owned by any mesh object"; return T3D_E_INVALID; }
+    phase("normals, plane groups");
     // Device order of the groups: by the axis of the largest normal component (that axis is dropped for the
     // in-plane coordinates), groups of one axis in order of their first triangle; groups of more than 24
     // triangles are cut into pieces (the hit flags of a group are the bits of a float32 integer).
@@ -2239,10 +2306,11 @@ static int upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
     const size_t G = pieces.size();
     std::vector<float4> planes(6 * (G + 1), make_float4(0.f, 0.f, 0.f, 0.f));
     std::vector<int> plane_first(G + 1, 0);
-    std::vector<float4> tri_uv((size_t)2 * (s->n_tris + 1), make_float4(0.f, 0.f, 0.f, 0.f));
-    std::vector<float4> tri_n((size_t)s->n_tris + 1, make_float4(0.f, 0.f, 0.f, 0.f));
-    std::vector<int4> meta((size_t)s->n_tris + 1, make_int4(0, 0, 0, 0));
-    std::vector<int> order((size_t)s->n_tris + 1, 0);  // device position -> index in the description
+    std::vector<float4> tri_uv((size_t)2 * ((want_bvh ? 0 : s->n_tris) + 1), make_float4(0.f, 0.f, 0.f, 0.f));   // in-plane rows: the brute-force loop's
+    HostArray<float4> tri_n((size_t)s->n_tris + 1);
+    HostArray<int4> meta((size_t)s->n_tris + 1);
+    HostArray<int> order((size_t)s->n_tris + 1);  // device position -> index in the description
+    tri_n[(size_t)s->n_tris] = make_float4(0.f, 0.f, 0.f, 0.f); meta[(size_t)s->n_tris] = make_int4(0, 0, 0, 0); order[(size_t)s->n_tris] = 0;   // (one spare entry each)
     {
         int k = 0;
         for (size_t g = 0; g < G; ++g) {
@@ -2277,12 +2345,14 @@ static int upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
         }
         plane_first[G] = k;
         if (want_bvh) {
-            for (int t = 0; t < s->n_tris; ++t) {
-                const Tri& T = tris[t];
-                tri_n[t] = make_float4((float)T.n[0], (float)T.n[1], (float)T.n[2], -(float)T.nv0 + 0.0f);
-                order[t] = t;
-                meta[t] = make_int4(T.obj, T.face, T.shader, t);
-            }
+            parallel_slices((size_t)s->n_tris, [&](size_t first, size_t last) {
+                for (size_t t = first; t < last; ++t) {
+                    const Tri& T = tris[t];
+                    tri_n[t] = make_float4((float)T.n[0], (float)T.n[1], (float)T.n[2], -(float)T.nv0 + 0.0f);
+                    order[t] = (int)t;
+                    meta[t] = make_int4(T.obj, T.face, T.shader, (int)t);
+                }
+            });
         }
         // Parallelograms: when the first two triangles of a group share an edge and their other two corners are
         // opposite corners of a parallelogram, the second triangle's barycentrics are the mirror image of the
@@ -2320,16 +2390,19 @@ static int upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
             planes[6 * g + 1].z = __builtin_bit_cast(float, 1);
         }
     }
+    phase("group and triangle rows");
     std::vector<DevShader> shaders((size_t)s->n_shaders);
     for (int k = 0; k < s->n_shaders; ++k) {
         shaders[k] = DevShader{(float)s->shader_color[3 * k], (float)s->shader_color[3 * k + 1], (float)s->shader_color[3 * k + 2],
                                (float)s->shader_rough[k], (float)s->shader_refl[k], (float)s->shader_emis[k], 0.f, 0.f};
     }
     std::vector<DevLight> lights = make_lights(c->sc, s);
-    std::vector<float4> prim_info(4 * std::max<size_t>(1, (size_t)s->n_tris + spheres.size()), make_float4(0.f, 0.f, 0.f, 0.f));   // never empty: a miss reads record 0
+    HostArray<float4> prim_info(4 * std::max<size_t>(1, (size_t)s->n_tris + spheres.size()));   // never empty: a miss reads record 0
+    if ((size_t)s->n_tris + spheres.size() == 0) for (int q = 0; q < 4; ++q) prim_info[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     {
         auto ib = [](int v) { return __builtin_bit_cast(float, v); };
-        for (int k = 0; k < s->n_tris; ++k) {
+        parallel_slices((size_t)s->n_tris, [&](size_t first, size_t last) {
+        for (size_t k = first; k < last; ++k) {
             const int4 m = meta[k];
             const DevShader& sh = shaders[m.z];
             const bool emitter = sh.emis > 0.0f;
@@ -2343,18 +2416,24 @@ static int upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
             prim_info[4 * (size_t)k + 2] = make_float4(sh.rough, sh.refl, sh.emis, emitter ? 1.0f : 1.0f - sh.refl);
             prim_info[4 * (size_t)k + 3] = make_float4(sh.r, sh.g, sh.b, 0.f);
         }
+        });
         for (size_t q = 0; q < spheres.size(); ++q) sphere_rows(spheres[q], s, &prim_info[4 * ((size_t)s->n_tris + q)]);
     }
+    phase("primitive records");
     int rc;
     if ((rc = upload(c, &c->d_prim_info, prim_info)) || (rc = upload(c, &c->d_planes, planes)) || (rc = upload(c, &c->d_plane_first, plane_first)) || (rc = upload(c, &c->d_tri_uv, tri_uv)) ||
         (rc = upload(c, &c->d_tri_n, tri_n)) || (rc = upload(c, &c->d_tri_meta, meta)) || (rc = upload(c, &c->d_spheres, spheres)) ||
         (rc = upload(c, &c->d_lights, lights)) || (rc = upload(c, &c->d_shaders, shaders)) || (rc = upload(c, &c->d_obj_ior, obj_ior)))
         return rc;
+    phase("copies to the device");
     if (want_bvh) {
         // 3-D barycentric rows  a = (e2 x n) / |n|^2, b = (n x e1) / |n|^2 :  P - v0 = u e1 + v e2  (float64, rounded once)
-        std::vector<float4> tri_ab((size_t)4 * (s->n_tris + 1), make_float4(0.f, 0.f, 0.f, 0.f));
-        std::vector<float> verts((size_t)9 * (s->n_tris + 1), 0.f);
-        for (int k = 0; k < s->n_tris; ++k) {
+        HostArray<float4> tri_ab((size_t)4 * (s->n_tris + 1));
+        HostArray<float> verts((size_t)9 * (s->n_tris + 1));
+        for (int q = 0; q < 4; ++q) tri_ab[4 * (size_t)s->n_tris + q] = make_float4(0.f, 0.f, 0.f, 0.f);   // (one spare entry each)
+        for (int q = 0; q < 9; ++q) verts[9 * (size_t)s->n_tris + q] = 0.f;
+        parallel_slices((size_t)s->n_tris, [&](size_t first, size_t last) {
+        for (size_t k = first; k < last; ++k) {
             const double* v = s->tri_verts + 9 * (size_t)order[k];
             for (int q = 0; q < 9; ++q) verts[9 * (size_t)k + q] = (float)v[q];
             const double e1[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]}, e2[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]};
@@ -2362,15 +2441,19 @@ static int upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
             const double nn = nx * nx + ny * ny + nz * nz;
             tri_ab[4 * (size_t)k + 0] = tri_n[k];
             tri_ab[4 * (size_t)k + 3] = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, order[k]));
+            tri_ab[4 * (size_t)k + 1] = tri_ab[4 * (size_t)k + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!(nn > 0)) continue;  // degenerate: rows stay zero, min3(u, v, w) = 0 is never inside
             const double a[3] = {(e2[1] * nz - e2[2] * ny) / nn, (e2[2] * nx - e2[0] * nz) / nn, (e2[0] * ny - e2[1] * nx) / nn};
             const double b[3] = {(ny * e1[2] - nz * e1[1]) / nn, (nz * e1[0] - nx * e1[2]) / nn, (nx * e1[1] - ny * e1[0]) / nn};
             tri_ab[4 * (size_t)k + 1] = make_float4((float)a[0], (float)a[1], (float)a[2], -(float)(a[0] * v[0] + a[1] * v[1] + a[2] * v[2]) + 0.0f);
             tri_ab[4 * (size_t)k + 2] = make_float4((float)b[0], (float)b[1], (float)b[2], -(float)(b[0] * v[0] + b[1] * v[1] + b[2] * v[2]) + 0.0f);
         }
+        });
+        phase("leaf rows");
         void* d_verts = nullptr;
         void* d_tri_ab = nullptr;   // records in device order; the build copies them into sorted leaf order
         if ((rc = upload(c, &d_tri_ab, tri_ab)) || (rc = upload(c, &d_verts, verts))) { hipFree(d_verts); hipFree(d_tri_ab); return rc; }
+        phase("their copies");
         float4* nodes = nullptr;
         float4* leaves = nullptr;
         // Few primitives: the hierarchy is built here, top-down by surface area (t3d_host_tree.h, t3d_set_host_tree_limit), at about 0.3 us a primitive;
@@ -2406,6 +2489,7 @@ static int upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
         hipError_t e = lbvh_build(c->stream, (const float*)d_verts, (const float4*)d_tri_ab, s->n_tris, (const DevSphere*)c->d_spheres,
                                   (int)spheres.size(), &nodes, &leaves, &c->lbvh_work, host_built ? &host_tree : nullptr);
         if (e != hipSuccess) { hipFree(d_verts); hipFree(d_tri_ab); c->err = std::string("t3d_upload_scene: LBVH build failed: ") + hipGetErrorString(e); return T3D_E_DEVICE; }
+        phase("hierarchy");
         c->d_lbvh_verts = d_verts; c->d_lbvh_tri_ab = d_tri_ab;   // kept for a refit (t3d_update_scene)
         c->d_bvh_nodes = nodes; c->d_bvh_leaves = leaves;
         // deep ends of traversal stacks, one piece per wave the traversal kernels can have in flight (never touched by the
@@ -2436,7 +2520,16 @@ static int upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
     d.geo.axis_end[0] = axis_count[0]; d.geo.axis_end[1] = axis_count[0] + axis_count[1]; d.geo.axis_end[2] = (int)G;
     d.geo.n_tris = s->n_tris; d.geo.n_spheres = (int)spheres.size();
     for (int a = 0; a < 3; ++a) { c->tri_lo[a] = INFINITY; c->tri_hi[a] = -INFINITY; }
-    for (size_t q = 0; q < (size_t)s->n_tris * 9; ++q) { c->tri_lo[q % 3] = fmin(c->tri_lo[q % 3], s->tri_verts[q]); c->tri_hi[q % 3] = fmax(c->tri_hi[q % 3], s->tri_verts[q]); }
+    {
+        std::mutex box_mutex;
+        parallel_slices((size_t)s->n_tris * 3, [&](size_t first, size_t last) {   // corners first .. last - 1
+            double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (size_t p = first; p < last; ++p)
+                for (int a = 0; a < 3; ++a) { const double x = s->tri_verts[3 * p + a]; lo[a] = fmin(lo[a], x); hi[a] = fmax(hi[a], x); }
+            std::lock_guard<std::mutex> lk(box_mutex);
+            for (int a = 0; a < 3; ++a) { c->tri_lo[a] = fmin(c->tri_lo[a], lo[a]); c->tri_hi[a] = fmax(c->tri_hi[a], hi[a]); }
+        });
+    }
     set_scene_box(c, spheres);
     d.n_planes = (int)G; d.n_tris = s->n_tris; d.n_spheres = (int)spheres.size(); d.n_lights = s->n_lights; d.n_shaders = s->n_shaders;
     d.tri_n = (const float4*)c->d_tri_n; d.tri_meta = (const int4*)c->d_tri_meta;
@@ -2449,6 +2542,7 @@ static int upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
     c->up_tris = s->n_tris; c->up_shaders = s->n_shaders; c->up_lights = s->n_lights;
     c->has_scene = true;
     c->scene_gen++;
+    phase("bounds, bookkeeping");
     return T3D_OK;
 }
 
