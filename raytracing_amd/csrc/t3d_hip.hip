@@ -2466,12 +2466,14 @@ static int upload_scene(t3d_ctx* c, const t3d_scene_desc* s) {
         bool host_built = n_prims >= 2 && n_prims <= host_max;
         auto prim_boxes = [&](std::vector<float>& blo, std::vector<float>& bhi) {   // boxes of the primitives in device order
             blo.resize(3 * (size_t)n_prims); bhi.resize(3 * (size_t)n_prims);
-            for (int k = 0; k < s->n_tris; ++k)
-                for (int a = 0; a < 3; ++a) {
-                    const float* v = &verts[9 * (size_t)k];
-                    blo[3 * (size_t)k + a] = fminf(fminf(v[a], v[3 + a]), v[6 + a]);
-                    bhi[3 * (size_t)k + a] = fmaxf(fmaxf(v[a], v[3 + a]), v[6 + a]);
-                }
+            parallel_slices((size_t)s->n_tris, [&](size_t first, size_t last) {
+                for (size_t k = first; k < last; ++k)
+                    for (int a = 0; a < 3; ++a) {
+                        const float* v = &verts[9 * k];
+                        blo[3 * k + a] = fminf(fminf(v[a], v[3 + a]), v[6 + a]);
+                        bhi[3 * k + a] = fmaxf(fmaxf(v[a], v[3 + a]), v[6 + a]);
+                    }
+            });
             for (size_t q = 0; q < spheres.size(); ++q) {
                 const DevSphere& sp = spheres[q];
                 const float r = sqrtf(sp.r2), ce[3] = {sp.cx, sp.cy, sp.cz};
@@ -2587,7 +2589,7 @@ static int adopt_background_tree(t3d_ctx* c, bool wait = false) {
     HIPCHK(c, hipMemcpyAsync(w.kids, t.kids.data(), sizeof(HostTreeKids) * (size_t)(n - 1), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(w.parent, t.parent.data(), sizeof(int) * (2 * (size_t)n - 1), hipMemcpyHostToDevice, c->stream));
     hipError_t e = lbvh_refit(c->stream, w, (const float*)c->d_lbvh_verts, (const float4*)c->d_lbvh_tri_ab, c->up_tris,
-                              (const DevSphere*)c->d_spheres, (int)c->h_spheres.size(), (float4*)c->d_bvh_nodes, (float4*)c->d_bvh_leaves);
+                              (const DevSphere*)c->d_spheres, (int)c->h_spheres.size(), (float4*)c->d_bvh_nodes, (float4*)c->d_bvh_leaves, true);
     if (e != hipSuccess) { c->err = std::string("background tree: refit failed: ") + hipGetErrorString(e); c->has_scene = false; return T3D_E_DEVICE; }
     HIPCHK(c, hipStreamSynchronize(c->stream));   // the tree's vectors go with `done`; callers' streams start after this
     c->tree_source = T3D_TREE_BACKGROUND;

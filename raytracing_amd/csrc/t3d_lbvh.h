@@ -28,6 +28,7 @@ struct LbvhWork {
     int* flags = nullptr;        // [N-1] arrival counters of the refit
     int* bounds = nullptr;       // [6] scene bounds as order-preserving ints
     int sorted = 0;              // keys[sorted] / vals[sorted] hold the sorted order (kept for lbvh_refit)
+    int rounds = 0;              // launches of k_lbvh_refit_round this tree's boxes take (its height); 0: not known yet, < 0: the climbing kernel instead
     void release() {
         hipFree(prim_lo); hipFree(prim_hi); hipFree(keys[0]); hipFree(keys[1]); hipFree(vals[0]); hipFree(vals[1]);
         hipFree(hist); hipFree(sums); hipFree(parent); hipFree(kids); hipFree(box_lo); hipFree(box_hi); hipFree(flags); hipFree(bounds);
@@ -235,6 +236,31 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_refit(const int* __restrict
     }
 }
 
+// The same boxes level by level, without a hand-over inside a launch: launch number r (1, 2, ...) finishes every node
+// whose children are leaves or were finished by an EARLIER launch (their flag holds that launch's number; a flag written
+// in this launch reads as r or as 0 and counts as not ready, so nothing depends on what one wave sees of another's
+// stores).  As many launches as the tree is high -- 30 to 45 for a million primitives, a few microseconds each once
+// most nodes are done and a thread leaves after one coalesced load -- against one launch of k_lbvh_refit, whose
+// agent-scope acquire-release per node costs an L2 write-back and invalidate each: 3.8 ms for a million primitives.
+__global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_refit_round(const int* __restrict__ vals, int n, const float4* __restrict__ prim_lo,
+                                                                 const float4* __restrict__ prim_hi, const int2* __restrict__ kids,
+                                                                 float4* box_lo, float4* box_hi, int* flags, int round) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1 || flags[i] != 0) return;
+    const int2 k = kids[i];
+    const bool leaf0 = k.x >= n - 1, leaf1 = k.y >= n - 1;
+    const int f0 = leaf0 ? 1 : flags[k.x], f1 = leaf1 ? 1 : flags[k.y];
+    if (!((leaf0 || (f0 != 0 && f0 < round)) && (leaf1 || (f1 != 0 && f1 < round)))) return;
+    float4 l0, h0, l1, h1;
+    if (leaf0) { const int p = vals[k.x - (n - 1)]; l0 = prim_lo[p]; h0 = prim_hi[p]; }
+    else { l0 = box_lo[k.x]; h0 = box_hi[k.x]; }
+    if (leaf1) { const int p = vals[k.y - (n - 1)]; l1 = prim_lo[p]; h1 = prim_hi[p]; }
+    else { l1 = box_lo[k.y]; h1 = box_hi[k.y]; }
+    box_lo[i] = make_float4(fminf(l0.x, l1.x), fminf(l0.y, l1.y), fminf(l0.z, l1.z), 0.f);
+    box_hi[i] = make_float4(fmaxf(h0.x, h1.x), fmaxf(h0.y, h1.y), fmaxf(h0.z, h1.z), 0.f);
+    flags[i] = round;
+}
+
 // Traversal nodes, 4 wide and quantised: the record of binary node i describes its GRANDchildren (a child that is
 // a leaf takes one slot itself), so one fetch decides four subtrees and a ray makes half as many dependent fetches
 // on its way down.  The traversal is bound by the number of 16-byte accesses a lane makes, not by arithmetic, so a
@@ -323,6 +349,44 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_leaves(const int* __restric
     }
 }
 
+// Boxes of the inner nodes from the boxes of the primitives.  `learn`: the tree is new -- rounds are launched in batches
+// until the root is done (its flag then holds the tree's height, kept in w.rounds; waits for the stream); a tree higher
+// than LBVH_MAX_ROUNDS gets the one-launch climbing kernel, now and at every refit.  Otherwise: w.rounds launches, not
+// waited for.
+#define LBVH_MAX_ROUNDS 128
+#define LBVH_ROUNDS_MIN_PRIMS 16384
+static hipError_t lbvh_node_boxes(hipStream_t st, LbvhWork& w, const int* vals, int n, bool learn) {
+    auto blocks = [](int k) { return dim3((unsigned)((k + LBVH_BLOCK - 1) / LBVH_BLOCK)); };
+    hipError_t e = hipMemsetAsync(w.flags, 0, sizeof(int) * (n - 1), st);
+    if (e != hipSuccess) return e;
+    auto round = [&](int r) {
+        hipLaunchKernelGGL(k_lbvh_refit_round, blocks(n - 1), dim3(LBVH_BLOCK), 0, st, vals, n, w.prim_lo, w.prim_hi, w.kids, w.box_lo, w.box_hi,
+                           w.flags, r);
+    };
+    // (few primitives: the one climbing launch is done before a tree's twenty-odd levels could be launched)
+    if (learn && n >= LBVH_ROUNDS_MIN_PRIMS && !getenv("T3D_LBVH_CLIMB")) {
+        w.rounds = -1;
+        for (int r = 0; r < LBVH_MAX_ROUNDS && w.rounds < 0;) {
+            for (int q = 0; q < 16; ++q) round(++r);
+            int root = 0;
+            if ((e = hipMemcpyAsync(&root, w.flags, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+            if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+            if (root > 0) w.rounds = root;
+        }
+        if (w.rounds > 0) return hipGetLastError();
+        if ((e = hipMemsetAsync(w.flags, 0, sizeof(int) * (n - 1), st)) != hipSuccess) return e;
+    } else if (learn) {
+        w.rounds = -1;
+    }
+    if (w.rounds > 0) {
+        for (int r = 1; r <= w.rounds; ++r) round(r);
+    } else {
+        hipLaunchKernelGGL(k_lbvh_refit, blocks(n), dim3(LBVH_BLOCK), 0, st, vals, n, w.prim_lo, w.prim_hi, w.kids, w.parent, w.box_lo, w.box_hi,
+                           w.flags);
+    }
+    return hipGetLastError();
+}
+
 // Build the hierarchy over n_tris triangles (vertices in device order, 9 floats each; d_tri_ab their 64-byte
 // intersection records in the same order) and n_spheres spheres; *out_nodes receives n - 1 traversal nodes and
 // *out_leaves n leaf records of 64 bytes each (hipMalloc, owned by the caller).  Needs n >= 2.
@@ -373,10 +437,8 @@ static hipError_t lbvh_build(hipStream_t st, const float* d_verts, const float4*
                            w.keys[cur ^ 1], w.vals[cur ^ 1]);
         cur ^= 1;
     }
-    LB(hipMemsetAsync(w.flags, 0, sizeof(int) * (n - 1), st));
     if (!host) hipLaunchKernelGGL(k_lbvh_hierarchy, blocks(n - 1), dim3(LBVH_BLOCK), 0, st, w.keys[cur], n, w.kids, w.parent);
-    hipLaunchKernelGGL(k_lbvh_refit, blocks(n), dim3(LBVH_BLOCK), 0, st, w.vals[cur], n, w.prim_lo, w.prim_hi, w.kids, w.parent, w.box_lo,
-                       w.box_hi, w.flags);
+    LB(lbvh_node_boxes(st, w, w.vals[cur], n, true));
     hipLaunchKernelGGL(k_lbvh_pack, blocks(n - 1), dim3(LBVH_BLOCK), 0, st, w.vals[cur], n, w.prim_lo, w.prim_hi, w.kids, w.box_lo, w.box_hi,
                        nodes);
     hipLaunchKernelGGL(k_lbvh_leaves, blocks(n), dim3(LBVH_BLOCK), 0, st, w.vals[cur], n, n_tris, d_tri_ab, d_spheres, leaves);
@@ -393,17 +455,17 @@ static hipError_t lbvh_build(hipStream_t st, const float* d_verts, const float4*
 // The same hierarchy after primitives have moved (spheres, Lights: the triangles are the caller's promise not to have):
 // boxes of the primitives again, boxes of the nodes bottom-up, records packed again.  The tree keeps its shape -- a sphere
 // that has travelled far sits in a larger box than a new build would give it, which costs visits, never hits.
+// new_tree: order, links and parents have been replaced (a hierarchy adopted from the host): its height is learnt again,
+// which waits for the stream.
 static hipError_t lbvh_refit(hipStream_t st, LbvhWork& w, const float* d_verts, const float4* d_tri_ab, int n_tris, const DevSphere* d_spheres,
-                             int n_spheres, float4* nodes, float4* leaves) {
+                             int n_spheres, float4* nodes, float4* leaves, bool new_tree = false) {
     const int n = n_tris + n_spheres;
     auto blocks = [](int k) { return dim3((unsigned)((k + LBVH_BLOCK - 1) / LBVH_BLOCK)); };
-    hipError_t e = hipMemsetAsync(w.flags, 0, sizeof(int) * (n - 1), st);
-    if (e != hipSuccess) return e;
     const int nb = (n + LBVH_BLOCK - 1) / LBVH_BLOCK;
     hipLaunchKernelGGL(k_lbvh_bounds, dim3((unsigned)(nb > 1024 ? 1024 : nb)), dim3(LBVH_BLOCK), 0, st, d_verts, n_tris, d_spheres, n_spheres,
                        w.prim_lo, w.prim_hi, w.bounds);
-    hipLaunchKernelGGL(k_lbvh_refit, blocks(n), dim3(LBVH_BLOCK), 0, st, w.vals[w.sorted], n, w.prim_lo, w.prim_hi, w.kids, w.parent, w.box_lo,
-                       w.box_hi, w.flags);
+    hipError_t e = lbvh_node_boxes(st, w, w.vals[w.sorted], n, new_tree);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_lbvh_pack, blocks(n - 1), dim3(LBVH_BLOCK), 0, st, w.vals[w.sorted], n, w.prim_lo, w.prim_hi, w.kids, w.box_lo, w.box_hi,
                        nodes);
     hipLaunchKernelGGL(k_lbvh_leaves, blocks(n), dim3(LBVH_BLOCK), 0, st, w.vals[w.sorted], n, n_tris, d_tri_ab, d_spheres, leaves);
