@@ -44,10 +44,11 @@ __device__ __forceinline__ float lbvh_o2f(int i) { return __int_as_float(i >= 0 
 // primitive it lies on, and the scene bounds.
 __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_bounds(const float* __restrict__ verts, int n_tris, const DevSphere* __restrict__ spheres,
                                                             int n_spheres, float4* __restrict__ prim_lo, float4* __restrict__ prim_hi,
-                                                            int* __restrict__ bounds) {
+                                                            int* __restrict__ bounds, int first = 0) {
+    // first: the primitives from this one on only (a refit: the triangles have not moved, first = n_tris)
     const int n = n_tris + n_spheres;
     float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    for (int p = first + blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
         float blo[3], bhi[3];
         if (p < n_tris) {
             const float* v = verts + 9 * (size_t)p;
@@ -461,9 +462,13 @@ static hipError_t lbvh_refit(hipStream_t st, LbvhWork& w, const float* d_verts, 
                              int n_spheres, float4* nodes, float4* leaves, bool new_tree = false) {
     const int n = n_tris + n_spheres;
     auto blocks = [](int k) { return dim3((unsigned)((k + LBVH_BLOCK - 1) / LBVH_BLOCK)); };
-    const int nb = (n + LBVH_BLOCK - 1) / LBVH_BLOCK;
-    hipLaunchKernelGGL(k_lbvh_bounds, dim3((unsigned)(nb > 1024 ? 1024 : nb)), dim3(LBVH_BLOCK), 0, st, d_verts, n_tris, d_spheres, n_spheres,
-                       w.prim_lo, w.prim_hi, w.bounds);
+    // the boxes of the spheres and Lights again; those of the triangles are the build's (the scene bounds, which only the
+    // Morton codes of a build use, take the new boxes in as well: harmless)
+    if (n_spheres > 0) {
+        const int nb = (n_spheres + LBVH_BLOCK - 1) / LBVH_BLOCK;
+        hipLaunchKernelGGL(k_lbvh_bounds, dim3((unsigned)(nb > 1024 ? 1024 : nb)), dim3(LBVH_BLOCK), 0, st, d_verts, n_tris, d_spheres, n_spheres,
+                           w.prim_lo, w.prim_hi, w.bounds, n_tris);
+    }
     hipError_t e = lbvh_node_boxes(st, w, w.vals[w.sorted], n, new_tree);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_lbvh_pack, blocks(n - 1), dim3(LBVH_BLOCK), 0, st, w.vals[w.sorted], n, w.prim_lo, w.prim_hi, w.kids, w.box_lo, w.box_hi,
