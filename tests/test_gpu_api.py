@@ -732,3 +732,45 @@ def test_bench_with_two_ranks_over_rccl():
     d = _run_bench_ranks(2, [])
     assert d["n_gpus"] == 2 and d["config"]["collective"] == "RCCL gather"
     _check_frame_counts(d)
+
+
+def test_demo_script_writes_the_scene_and_the_picture(tmp_path, monkeypatch, oracle_mod):
+    """cornell_test.py, the counterpart of the reference's demo script (cornellTest.py:7-155): the scene it builds through
+    the API loads again from the JSON it writes (same geometry), the PNG holds the frame it rendered, and the frame is the oracle's."""
+    import json
+    import struct
+    import sys
+    import zlib
+    import cornell_test
+    import T3DE
+    from raytracing_amd.flatten import flatten_scene
+    out = tmp_path / "renders"
+    monkeypatch.setattr(sys, "argv", ["cornell_test.py", "--width", "64", "--height", "40", "--bounces", "2", "--samples", "2", "--seed", "5",
+                                      "--light", "--out", str(out)])
+    render = cornell_test.main()
+    files = sorted(p.name for p in out.iterdir())
+    assert files[0] == "cornellScene.json" and files[1].startswith("cornell|") and files[1].endswith(f"|{render.rays}.png")
+    from raytracing_amd.workloads import cornell_scene
+    flat = flatten_scene(cornell_scene(with_light=True))
+    again = flatten_scene(T3DE.Scene.fromDict(json.load(open(out / "cornellScene.json"))))   # (the loader puts the camera first)
+    assert again.n_tris == flat.n_tris and again.n_spheres == flat.n_spheres and len(again.light_strength) == len(flat.light_strength)
+    assert np.array_equal(np.sort(again.tri_verts.reshape(-1, 9), axis=0), np.sort(flat.tri_verts.reshape(-1, 9), axis=0))
+    opt = dict(width=64, height=40, bounces=2, samples=2, ambient=(32, 32, 32))
+    ref = oracle_mod.render(flat, opt, seed=5)
+    img = render.imageAs("np")                                   # RGB
+    diff = np.abs(img.astype(int) - ref["bgr"][:, :, ::-1].astype(int)).max(axis=2)
+    assert (diff <= 1).mean() >= 0.999 and render.rays == ref["stats"]["rays_api"]
+    # the PNG: 8-bit RGB, one filter byte per row, the same pixels
+    data = open(out / files[1], "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, size = 8, b"", None
+    while pos < len(data):
+        n, tag = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        if tag == b"IHDR":
+            size = struct.unpack(">II", body[:8])
+        if tag == b"IDAT":
+            idat += body
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(size[1], 1 + 3 * size[0])
+    assert size == (64, 40) and (raw[:, 0] == 0).all() and np.array_equal(raw[:, 1:].reshape(40, 64, 3), img)
