@@ -2069,7 +2069,16 @@ static void sphere_rows(const DevSphere& sp, const t3d_scene_desc* s, float4* ro
     rows[3] = make_float4((float)s->shader_color[3 * sp.shader], (float)s->shader_color[3 * sp.shader + 1], (float)s->shader_color[3 * sp.shader + 2], 0.f);
 }
 static const char* not_finite(const t3d_scene_desc* s, bool triangles) {
-    auto finite = [](const double* p, size_t n) { if (p) for (size_t i = 0; i < n; ++i) if (!std::isfinite(p[i])) return false; return true; };
+    auto finite = [](const double* p, size_t n) {
+        if (!p) return true;
+        std::atomic<bool> all{true};
+        parallel_slices(n, [&](size_t first, size_t last) {
+            bool good = true;
+            for (size_t i = first; i < last; ++i) good &= std::isfinite(p[i]);
+            if (!good) all.store(false, std::memory_order_relaxed);
+        });
+        return all.load();
+    };
     return triangles && !finite(s->tri_verts, (size_t)s->n_tris * 9) ? "a triangle corner"
          : !finite(s->obj_center, (size_t)s->n_objects * 3) ? "an object position"
          : !finite(s->obj_radius, (size_t)s->n_objects) ? "an object radius"
