@@ -444,6 +444,7 @@ def main():
                        # none: brute force; device: Morton order; host: surface area, cut during the upload; background: the
                        # same, cut on a host thread during the first untimed frames (--background-tree)
                        "hierarchy": "/".join(hierarchy),
+                       "untimed_calls_per_chain": max(warm // F, WARM_CALLS_PER_CHAIN),
                        # averages over the timed frames (exact: every timed call was rendered again with statistics)
                        "queries_per_frame": round(traced / steps, 1),
                        "shadow_rays_answered_untraced_per_frame": round(totals["shadow_culled"] / steps, 1),
