@@ -2594,13 +2594,15 @@ static int adopt_background_tree(t3d_ctx* c, bool wait = false) {
     if (c->last_stream && c->last_stream != c->stream && hipStreamSynchronize(c->last_stream) != hipSuccess) (void)hipGetLastError();
     LbvhWork& w = c->lbvh_work;
     const HostTree& t = done->tree;
-    HIPCHK(c, hipMemcpyAsync(w.vals[w.sorted], t.order.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(w.kids, t.kids.data(), sizeof(HostTreeKids) * (size_t)(n - 1), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(w.parent, t.parent.data(), sizeof(int) * (2 * (size_t)n - 1), hipMemcpyHostToDevice, c->stream));
-    hipError_t e = lbvh_refit(c->stream, w, (const float*)c->d_lbvh_verts, (const float4*)c->d_lbvh_tri_ab, c->up_tris,
-                              (const DevSphere*)c->d_spheres, (int)c->h_spheres.size(), (float4*)c->d_bvh_nodes, (float4*)c->d_bvh_leaves, true);
-    if (e != hipSuccess) { c->err = std::string("background tree: refit failed: ") + hipGetErrorString(e); c->has_scene = false; return T3D_E_DEVICE; }
-    HIPCHK(c, hipStreamSynchronize(c->stream));   // the tree's vectors go with `done`; callers' streams start after this
+    // from the first copy on a failure leaves order, links and records that do not belong together: the scene is gone then
+    hipError_t e = hipMemcpyAsync(w.vals[w.sorted], t.order.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(w.kids, t.kids.data(), sizeof(HostTreeKids) * (size_t)(n - 1), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(w.parent, t.parent.data(), sizeof(int) * (2 * (size_t)n - 1), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess)
+        e = lbvh_refit(c->stream, w, (const float*)c->d_lbvh_verts, (const float4*)c->d_lbvh_tri_ab, c->up_tris, (const DevSphere*)c->d_spheres,
+                       (int)c->h_spheres.size(), (float4*)c->d_bvh_nodes, (float4*)c->d_bvh_leaves, true);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // the tree's vectors go with `done`; callers' streams start after this
+    if (e != hipSuccess) { c->err = std::string("background tree: could not be put in place: ") + hipGetErrorString(e); c->has_scene = false; return T3D_E_DEVICE; }
     c->tree_source = T3D_TREE_BACKGROUND;
     return T3D_OK;
 }
